@@ -1,0 +1,354 @@
+"""ctypes binding of the CPU oracle (oracle/libsaf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py — never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent
+TABLES = ROOT / "spatial_audio_framework_amd" / "data" / "saf_tables.bin"
+_LIB = None
+
+c_f = C.POINTER(C.c_float)
+c_d = C.POINTER(C.c_double)
+c_i = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+def build(force=False):
+    so = HERE / "libsaf_oracle.so"
+    srcs = [HERE / n for n in ("orc_core.c", "orc_sh.c", "orc_examples.c", "saf_oracle.h")]
+    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", str(HERE)])
+    if Path("/root/reference/framework/resources/kissFFT/kiss_fftr.c").exists():
+        ref = HERE / "_ref" / "libkissfft_ref.so"
+        if force or not ref.exists():
+            subprocess.check_call(["make", "-s", "-C", str(HERE), "ref"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = build()
+        L = C.CDLL(str(so))
+        L.orc_tables_load.argtypes = [C.c_char_p]
+        L.orc_tables_load.restype = C.c_int
+        rc = L.orc_tables_load(str(TABLES).encode())
+        if rc != 0:
+            raise RuntimeError(f"oracle: cannot load tables {TABLES} (rc={rc})")
+        L.orc_table.restype = c_f
+        L.orc_table.argtypes = [C.c_char_p, c_i, c_i]
+        L.orc_ambi_dec_getDecMtx.restype = c_f
+        L.orc_ambi_dec_getFreqVector.restype = c_f
+        L.orc_ambi_dec_getMnorm.restype = C.c_float
+        L.orc_afSTFT_getNBands.restype = C.c_int
+        L.orc_afSTFT_getProcDelay.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def fptr(a):
+    return a.ctypes.data_as(c_f)
+
+
+def table(name):
+    d0, d1 = C.c_int(), C.c_int()
+    p = lib().orc_table(name.encode(), C.byref(d0), C.byref(d1))
+    if not p:
+        raise KeyError(name)
+    return np.ctypeslib.as_array(p, shape=(d0.value, d1.value)).copy()
+
+
+# ------------------------------------------------------------------ FFT
+class RFFT:
+    def __init__(self, N):
+        self.N = N
+        self.h = vp()
+        lib().orc_rfft_create(C.byref(self.h), C.c_int(N))
+
+    def forward(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(self.N // 2 + 1, np.complex64)
+        lib().orc_rfft_forward(self.h, fptr(x), out.ctypes.data_as(vp))
+        return out
+
+    def backward(self, X):
+        X = np.ascontiguousarray(X, np.complex64)
+        out = np.zeros(self.N, np.float32)
+        lib().orc_rfft_backward(self.h, X.ctypes.data_as(vp), fptr(out))
+        return out
+
+    def __del__(self):
+        if self.h:
+            lib().orc_rfft_destroy(C.byref(self.h))
+
+
+# ------------------------------------------------------------------ afSTFT
+class AfSTFT:
+    """afSTFT oracle; spectra returned as [nBands][dataFD_nCH][nHops] complex64."""
+
+    def __init__(self, nCHin, nCHout, hopsize=128, lowDelay=0, hybrid=1, fmt=0):
+        self.h = vp()
+        self.nCHin, self.nCHout, self.hop = nCHin, nCHout, hopsize
+        lib().orc_afSTFT_create(C.byref(self.h), nCHin, nCHout, hopsize, lowDelay, hybrid, fmt)
+        self.nBands = lib().orc_afSTFT_getNBands(self.h)
+        self.delay = lib().orc_afSTFT_getProcDelay(self.h)
+
+    def forward(self, x, nCH_alloc=None):
+        x = np.ascontiguousarray(x, np.float32)
+        nCH, F = x.shape
+        assert nCH == self.nCHin
+        nH = F // self.hop
+        nA = nCH_alloc or nCH
+        out = np.zeros((self.nBands, nA, nH), np.complex64)
+        lib().orc_afSTFT_forward_knownDimensions(self.h, fptr(x), F, nA, nH, out.ctypes.data_as(vp))
+        return out
+
+    def backward(self, X):
+        X = np.ascontiguousarray(X, np.complex64)
+        nB, nA, nH = X.shape
+        F = nH * self.hop
+        out = np.zeros((self.nCHout, F), np.float32)
+        lib().orc_afSTFT_backward_knownDimensions(self.h, X.ctypes.data_as(vp), F, nA, nH, fptr(out))
+        return out
+
+    def channelChange(self, nin, nout):
+        lib().orc_afSTFT_channelChange(self.h, nin, nout)
+        self.nCHin, self.nCHout = nin, nout
+
+    def clearBuffers(self):
+        lib().orc_afSTFT_clearBuffers(self.h)
+
+    def centreFreqs(self, fs):
+        f = np.zeros(self.nBands, np.float32)
+        lib().orc_afSTFT_getCentreFreqs(self.h, C.c_float(fs), self.nBands, fptr(f))
+        return f
+
+    def __del__(self):
+        if self.h:
+            lib().orc_afSTFT_destroy(C.byref(self.h))
+
+
+def centreFreqs_nullHandle(fs):
+    f = np.zeros(133, np.float32)
+    lib().orc_afSTFT_getCentreFreqs(None, C.c_float(fs), 133, fptr(f))
+    return f
+
+
+def FIRtoFilterbankCoeffs(hIR, hop=128, LD=0, hybrid=1):
+    hIR = np.ascontiguousarray(hIR, np.float32)
+    nd, nch, L = hIR.shape
+    nB = hop + (5 if hybrid else 1)
+    out = np.zeros((nB, nch, nd), np.complex64)
+    lib().orc_afSTFT_FIRtoFilterbankCoeffs(fptr(hIR), nd, nch, L, hop, LD, hybrid, out.ctypes.data_as(vp))
+    return out
+
+
+# ------------------------------------------------------------------ SH / HOA
+def _sh(fn, order, dirs):
+    dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 2)
+    Y = np.zeros(((order + 1) ** 2, dirs.shape[0]), np.float32)
+    getattr(lib(), fn)(order, fptr(dirs), dirs.shape[0], fptr(Y))
+    return Y
+
+
+def getSHreal(order, dirs_rad): return _sh("orc_getSHreal", order, dirs_rad)
+def getSHreal_recur(order, dirs_rad): return _sh("orc_getSHreal_recur", order, dirs_rad)
+def getRSH(order, dirs_deg): return _sh("orc_getRSH", order, dirs_deg)
+def getRSH_recur(order, dirs_deg): return _sh("orc_getRSH_recur", order, dirs_deg)
+
+
+def getMaxREweights(order, diag=False):
+    n = (order + 1) ** 2
+    a = np.zeros((n, n) if diag else n, np.float32)
+    lib().orc_getMaxREweights(order, int(diag), fptr(a))
+    return a
+
+
+def getLoudspeakerDecoderMtx(ls_dirs_deg, method, order, maxrE=0):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    M = np.zeros((d.shape[0], (order + 1) ** 2), np.float32)
+    lib().orc_getLoudspeakerDecoderMtx(fptr(d), d.shape[0], method, order, maxrE, fptr(M))
+    return M
+
+
+def pinv(A):
+    A = np.ascontiguousarray(A, np.float32)
+    out = np.zeros((A.shape[1], A.shape[0]), np.float32)
+    lib().orc_pinv(fptr(A), A.shape[0], A.shape[1], fptr(out))
+    return out
+
+
+def findLsTriplets(ls_dirs_deg, omitLarge=0):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    verts, faces = c_f(), c_i()
+    nv, nf = C.c_int(), C.c_int()
+    lib().orc_findLsTriplets(fptr(d), d.shape[0], omitLarge, C.byref(verts), C.byref(nv), C.byref(faces), C.byref(nf))
+    V = np.ctypeslib.as_array(verts, shape=(nv.value, 3)).copy()
+    Fc = np.ctypeslib.as_array(faces, shape=(nf.value, 3)).copy() if nf.value else np.zeros((0, 3), np.int32)
+    return V, Fc
+
+
+def generateVBAPgainTable3D_srcs(src_dirs_deg, ls_dirs_deg, omitLarge=0, dummies=0, spread=0.0):
+    s = np.ascontiguousarray(src_dirs_deg, np.float32).reshape(-1, 2)
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    g = c_f()
+    n, nt = C.c_int(), C.c_int()
+    lib().orc_generateVBAPgainTable3D_srcs(fptr(s), s.shape[0], fptr(d), d.shape[0], omitLarge, dummies, C.c_float(spread),
+                                           C.byref(g), C.byref(n), C.byref(nt))
+    return np.ctypeslib.as_array(g, shape=(n.value, d.shape[0])).copy(), nt.value
+
+
+def generateVBAPgainTable3D(ls_dirs_deg, az_res, el_res, omitLarge=0, dummies=0, spread=0.0):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    g = c_f()
+    n, nt = C.c_int(), C.c_int()
+    lib().orc_generateVBAPgainTable3D(fptr(d), d.shape[0], az_res, el_res, omitLarge, dummies, C.c_float(spread),
+                                      C.byref(g), C.byref(n), C.byref(nt))
+    return np.ctypeslib.as_array(g, shape=(n.value, d.shape[0])).copy(), nt.value
+
+
+def compressVBAPgainTable3D(gt):
+    gt = np.ascontiguousarray(gt, np.float32)
+    comp = np.zeros((gt.shape[0], 3), np.float32)
+    idx = np.zeros((gt.shape[0], 3), np.int32)
+    lib().orc_compressVBAPgainTable3D(fptr(gt), gt.shape[0], gt.shape[1], fptr(comp), idx.ctypes.data_as(c_i))
+    return comp, idx
+
+
+# ------------------------------------------------------------------ operators
+def _chan_ptrs(a):
+    arr = (c_f * a.shape[0])()
+    for i in range(a.shape[0]):
+        arr[i] = a[i].ctypes.data_as(c_f)
+    return arr
+
+
+class AmbiDec:
+    def __init__(self, frameSize=512):
+        self.h = vp()
+        self.F = frameSize
+        lib().orc_ambi_dec_create(C.byref(self.h), frameSize)
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_ambi_dec_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def setLoudspeakersDeg(self, dirs):
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 2)
+        lib().orc_ambi_dec_setLoudspeakers(self.h, fptr(d), d.shape[0])
+
+    def process(self, x, nOut):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((nOut, self.F), np.float32)
+        lib().orc_ambi_dec_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, x.shape[1])
+        return y
+
+    def decMtx(self, dec, order, maxrE, nLS):
+        p = lib().orc_ambi_dec_getDecMtx(self.h, dec, order, maxrE)
+        return np.ctypeslib.as_array(p, shape=(nLS, (order + 1) ** 2)).copy()
+
+    def Mnorm(self, dec, order, which):
+        return lib().orc_ambi_dec_getMnorm(self.h, dec, order, which)
+
+    def freqVector(self):
+        return np.ctypeslib.as_array(lib().orc_ambi_dec_getFreqVector(self.h), shape=(133,)).copy()
+
+    def stageTimes(self):
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        lib().orc_ambi_dec_getStageTimes(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def __del__(self):
+        if self.h:
+            lib().orc_ambi_dec_destroy(C.byref(self.h))
+
+
+class AmbiEnc:
+    def __init__(self, frameSize=64):
+        self.h = vp()
+        self.F = frameSize
+        lib().orc_ambi_enc_create(C.byref(self.h), frameSize)
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_ambi_enc_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nOut):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((nOut, self.F), np.float32)
+        lib().orc_ambi_enc_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, x.shape[1])
+        return y
+
+    def __del__(self):
+        if self.h:
+            lib().orc_ambi_enc_destroy(C.byref(self.h))
+
+
+class MatrixConv:
+    def __init__(self, hop, H, part=1):
+        H = np.ascontiguousarray(H, np.float32)
+        self.nOut, self.nIn, self.L = H.shape
+        self.hop = hop
+        self.h = vp()
+        lib().orc_matrixConv_create(C.byref(self.h), hop, fptr(H), self.L, self.nIn, self.nOut, part)
+
+    def apply(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((self.nOut, self.hop), np.float32)
+        lib().orc_matrixConv_apply(self.h, fptr(x), fptr(y))
+        return y
+
+    def __del__(self):
+        if self.h:
+            lib().orc_matrixConv_destroy(C.byref(self.h))
+
+
+def binaural_mac(inTF, hrtf, nSrc, scale):
+    """inTF [nBands][nSrcStride][T] c64, hrtf [nSrc][nBands][2] c64 -> [nBands][2][T]."""
+    inTF = np.ascontiguousarray(inTF, np.complex64)
+    hrtf = np.ascontiguousarray(hrtf, np.complex64)
+    nB, stride, T = inTF.shape
+    out = np.zeros((nB, 2, T), np.complex64)
+    lib().orc_binaural_mac(inTF.ctypes.data_as(vp), hrtf.ctypes.data_as(vp), nB, nSrc, stride, T, C.c_float(scale), out.ctypes.data_as(vp))
+    return out
+
+
+# ------------------------------------------------------------------ the reference's own KissFFT (oracle/_ref)
+class KissRef:
+    """kiss_fftr / kiss_fftri compiled from /root/reference (only where that checkout exists)."""
+
+    class _cpx(C.Structure):
+        _fields_ = [("r", C.c_float), ("i", C.c_float)]
+
+    @staticmethod
+    def available():
+        return (HERE / "_ref" / "libkissfft_ref.so").exists()
+
+    def __init__(self, N):
+        self.L = C.CDLL(str(HERE / "_ref" / "libkissfft_ref.so"))
+        self.L.kiss_fftr_alloc.restype = vp
+        self.L.kiss_fftr_alloc.argtypes = [C.c_int, C.c_int, vp, vp]
+        self.N = N
+        self.fwd = vp(self.L.kiss_fftr_alloc(N, 0, None, None))
+        self.inv = vp(self.L.kiss_fftr_alloc(N, 1, None, None))
+
+    def forward(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros(self.N // 2 + 1, np.complex64)
+        self.L.kiss_fftr(self.fwd, fptr(x), out.ctypes.data_as(vp))
+        return out
+
+    def backward(self, X):
+        """saf_rfft_backward semantics: kiss_fftri then scale 1/N (saf_utility_fft.c:749-752)."""
+        X = np.ascontiguousarray(X, np.complex64)
+        out = np.zeros(self.N, np.float32)
+        self.L.kiss_fftri(self.inv, X.ctypes.data_as(vp), fptr(out))
+        return out * np.float32(1.0 / self.N)

@@ -1,0 +1,134 @@
+/*
+ * saf_oracle.h — CPU restatement of the SAF per-block rendering hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+ * product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may build, load or call it, and only as the checker.  The product
+ * (spatial_audio_framework_amd/csrc -> libsaf_hip.so) never links or calls it.
+ *
+ * Plain C (gcc), scalar, single thread, float arithmetic in the same order as
+ * the reference wherever that order is observable.  Every function cites the
+ * reference file:line it restates (paths relative to /root/reference).
+ *
+ * Pinning: the full reference cannot be built in this image
+ * (it needs CBLAS/LAPACKE headers and a default-HRIR source file that are
+ * absent), so the oracle is pinned by
+ *   (1) the reference's own unit tests restated in tests/test_oracle_*.py
+ *       (test__afSTFT, test__saf_rfft, test__getSHreal(_recur),
+ *        test__getLoudspeakerDecoderMtx, test__saf_example_ambi_enc/_ambi_dec),
+ *   (2) the known-answer values recorded from a reference run in SURVEY.md §8c,
+ *   (3) oracle/_ref: the reference's vendored KissFFT, which DOES compile from
+ *       its own two source files, for the real-FFT convention,
+ *   (4) independent float64 closed forms (direct convolution, direct DFT).
+ */
+#ifndef SAF_ORACLE_H
+#define SAF_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } orc_cpx;
+
+/* ---- data tables (spatial_audio_framework_amd/data/saf_tables.bin) ---- */
+int          orc_tables_load(const char* path);              /* 0 on success */
+const float* orc_table(const char* name, int* d0, int* d1);   /* NULL if absent */
+
+/* ---- real FFT, saf_rfft semantics (saf_utility_fft.c:531-753) ---- */
+void orc_rfft_create(void** ph, int N);
+void orc_rfft_destroy(void** ph);
+void orc_rfft_forward(void* h, const float* in, orc_cpx* out);   /* unscaled, N/2+1 bins */
+void orc_rfft_backward(void* h, const orc_cpx* in, float* out);  /* scaled 1/N */
+
+/* ---- afSTFT (afSTFTlib.c / afSTFT_internal.c) ---- */
+#define ORC_AFSTFT_BANDS_CH_TIME 0
+#define ORC_AFSTFT_TIME_CH_BANDS 1
+void orc_afSTFT_create(void** ph, int nCHin, int nCHout, int hopsize, int lowDelayMode, int hybridmode, int format);
+void orc_afSTFT_destroy(void** ph);
+/* dataTD: flat [nCH][framesize]; dataFD flat with the "knownDimensions" strides */
+void orc_afSTFT_forward_knownDimensions(void* h, const float* dataTD, int framesize, int dataFD_nCH, int dataFD_nHops, orc_cpx* dataFD);
+void orc_afSTFT_backward_knownDimensions(void* h, const orc_cpx* dataFD, int framesize, int dataFD_nCH, int dataFD_nHops, float* dataTD);
+void orc_afSTFT_channelChange(void* h, int new_nCHin, int new_nCHout);
+void orc_afSTFT_clearBuffers(void* h);
+int  orc_afSTFT_getNBands(void* h);
+int  orc_afSTFT_getProcDelay(void* h);
+void orc_afSTFT_getCentreFreqs(void* h /* may be NULL */, float fs, int nBands, float* freqVector);
+void orc_afSTFT_FIRtoFilterbankCoeffs(const float* hIR, int N_dirs, int nCH, int ir_len, int hopSize, int LDmode, int hybridmode, orc_cpx* hFB);
+
+/* ---- spherical harmonics (saf_sh.c, saf_hoa.c) ---- */
+void orc_unnorm_legendreP(int n, const double* x, int lenX, double* y);
+void orc_getSHreal(int order, const float* dirs_rad, int nDirs, float* Y);
+void orc_getSHreal_recur(int order, const float* dirs_rad, int nDirs, float* Y);
+void orc_getRSH(int order, const float* dirs_deg, int nDirs, float* Y);
+void orc_getRSH_recur(int order, const float* dirs_deg, int nDirs, float* Y);
+void orc_getMaxREweights(int order, int diagMtxFlag, float* a_n);
+void orc_convertHOAChannelConvention(float* insig, int order, int signalLength, int inConv, int outConv); /* 1 ACN, 2 FuMa */
+void orc_convertHOANormConvention(float* insig, int order, int signalLength, int inConv, int outConv);    /* 1 N3D, 2 SN3D, 3 FuMa */
+
+/* ---- loudspeaker decoders (saf_hoa.c:326-392, saf_hoa_internal.c:41-155) ---- */
+#define ORC_DECODER_DEFAULT 0
+#define ORC_DECODER_SAD     1
+#define ORC_DECODER_MMD     2
+#define ORC_DECODER_EPAD    3
+#define ORC_DECODER_ALLRAD  4
+void orc_getLoudspeakerDecoderMtx(const float* ls_dirs_deg, int nLS, int method, int order, int enableMaxrE, float* decMtx);
+void orc_pinv(const float* inM, int dim1, int dim2, float* outM);  /* utility_spinv, saf_utility_veclib.c:3466 */
+
+/* ---- VBAP (saf_vbap.c) ---- */
+int  orc_findLsTriplets(const float* ls_dirs_deg, int L, int omitLargeTriangles, float** out_vertices, int* numOutVertices, int** out_faces, int* numOutFaces);
+void orc_invertLsMtx3D(const float* U_spkr, const int* ls_groups, int N_group, float* layoutInvMtx);
+void orc_vbap3D(const float* src_dirs, int src_num, int ls_num, const int* ls_groups, int nFaces, float spread, const float* layoutInvMtx, float** GainMtx);
+void orc_generateVBAPgainTable3D_srcs(const float* src_dirs_deg, int S, const float* ls_dirs_deg, int L, int omitLargeTriangles, int enableDummies, float spread, float** gtable, int* N_gtable, int* nTriangles);
+void orc_generateVBAPgainTable3D(const float* ls_dirs_deg, int L, int az_res_deg, int el_res_deg, int omitLargeTriangles, int enableDummies, float spread, float** gtable, int* N_gtable, int* nTriangles);
+void orc_compressVBAPgainTable3D(const float* vbap_gtable, int nTable, int nDirs, float* vbap_gtableComp, int* vbap_gtableIdx);
+
+/* ---- ambi_dec (examples/src/ambi_dec/ambi_dec.c) — loudspeaker output path ---- */
+void orc_ambi_dec_create(void** ph, int frameSize);
+void orc_ambi_dec_destroy(void** ph);
+void orc_ambi_dec_init(void* h, int sampleRate);
+void orc_ambi_dec_initCodec(void* h);
+void orc_ambi_dec_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
+void orc_ambi_dec_setMasterDecOrder(void* h, int order);
+void orc_ambi_dec_setDecOrder(void* h, int order, int band);
+void orc_ambi_dec_setDecOrderAllBands(void* h, int order);
+void orc_ambi_dec_setLoudspeakers(void* h, const float* dirs_deg, int nLS);
+void orc_ambi_dec_setOutputConfigPreset(void* h, int presetID);
+void orc_ambi_dec_setChOrder(void* h, int newOrder);
+void orc_ambi_dec_setNormType(void* h, int newType);
+void orc_ambi_dec_setDecMethod(void* h, int index, int newID);
+void orc_ambi_dec_setDecEnableMaxrE(void* h, int index, int newID);
+void orc_ambi_dec_setDecNormType(void* h, int index, int newID);
+void orc_ambi_dec_setTransitionFreq(void* h, float newValue);
+int  orc_ambi_dec_getNumLoudspeakers(void* h);
+const float* orc_ambi_dec_getDecMtx(void* h, int dec, int order, int maxrE);   /* [nLS x nSH_order] */
+float orc_ambi_dec_getMnorm(void* h, int dec, int order, int which);
+const float* orc_ambi_dec_getFreqVector(void* h);
+/* stage timers for the cpu_baseline split (seconds accumulated) */
+void orc_ambi_dec_getStageTimes(void* h, double* fwd, double* dec, double* bwd);
+
+/* ---- ambi_enc (examples/src/ambi_enc/ambi_enc.c) ---- */
+void orc_ambi_enc_create(void** ph, int frameSize);
+void orc_ambi_enc_destroy(void** ph);
+void orc_ambi_enc_init(void* h, int sampleRate);
+void orc_ambi_enc_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
+void orc_ambi_enc_setOutputOrder(void* h, int order);
+void orc_ambi_enc_setNumSources(void* h, int n);
+void orc_ambi_enc_setSourceAzi_deg(void* h, int idx, float azi);
+void orc_ambi_enc_setSourceElev_deg(void* h, int idx, float elev);
+void orc_ambi_enc_setSourceGain(void* h, int idx, float g);
+void orc_ambi_enc_setChOrder(void* h, int v);
+void orc_ambi_enc_setNormType(void* h, int v);
+void orc_ambi_enc_setEnablePostScaling(void* h, int v);
+
+/* ---- matrix convolver (saf_utility_matrixConv.c:37-236) ---- */
+void orc_matrixConv_create(void** ph, int hopSize, const float* H, int length_h, int nCHin, int nCHout, int usePartFLAG);
+void orc_matrixConv_destroy(void** ph);
+void orc_matrixConv_apply(void* h, const float* in, float* out);
+
+/* ---- binauraliser block path (binauraliser.c:191-285) with caller-supplied per-source HRTF band coefficients ---- */
+void orc_binaural_mac(const orc_cpx* inTF /* [nBands][nSrcStride][T] */, const orc_cpx* hrtf /* [nSrc][nBands][2] */,
+                      int nBands, int nSrc, int nSrcStride, int T, float scale, orc_cpx* outTF /* [nBands][2][T] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
