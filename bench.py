@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — audio-frames/s of the 7th-order ambi_dec hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): order-7 ambi_dec, 64 SH in ->
+64 loudspeakers out (SphCovering-64, SAD, maxrE, energy-preserving), 512-sample
+blocks, synthetic uniform noise resident in HBM.  One *step* = one batched pass
+of the hot path over `instances` independent decoder instances x
+`frames_per_call` consecutive blocks (= instances*frames_per_call frames).
+Instances are independent, so N GPUs run N times the instances (weak scaling,
+no data-path collective); ranks only meet in the barriers and the max-reduce
+of the elapsed time.
+
+Emits ONE JSON line with the contract fields plus
+  roofline     — for the kernel with the largest share of the step, from HIP
+                 events recorded on the launch stream around every kernel of
+                 the timed region (saf_hip_profile_*);
+  cpu_baseline — the CPU oracle (a port of the reference path, scalar, 1 core)
+                 timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+FRAME = 512
+NCH = 64
+ALG_BYTES_PER_FRAME = {            # DESIGN.md §"Roofline accounting"
+    "afstft_analysis": NCH * FRAME * 4 + 133 * NCH * 4 * 8,      # samples in + spectra out
+    "band_gemm": 2 * 133 * NCH * 4 * 8,                           # spectra in + spectra out
+    "afstft_synthesis": 133 * NCH * 4 * 8 + NCH * FRAME * 4,     # spectra in + samples out
+}
+PATH_BYTES_PER_FRAME = 2 * NCH * FRAME * 4                        # 262 144 B / frame
+GEMM_FLOP_PER_FRAME = 133 * 4 * 64 * 64 * 4                       # 8.72 MFLOP / frame (real matrix x complex data)
+HBM_PEAK_GBS = 8000.0                                             # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3                                      # dense fp32-input MFMA peak
+
+
+def make_decoder(api_mod, cls):
+    d = cls(FRAME)
+    d.setNormType(1)                 # NORM_N3D
+    d.setChOrder(1)                  # CH_ACN
+    d.setMasterDecOrder(7)
+    d.setOutputConfigPreset(29)      # LOUDSPEAKER_ARRAY_PRESET_SPH_COV_64
+    d.setDecMethod(0, 1)             # SAD below the transition
+    d.setDecMethod(1, 1)             # SAD above
+    d.initCodec()
+    d.init(48000)
+    d.setDecOrderAllBands(7)
+    return d
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """Oracle (port of the reference CPU path) on 1 core, same configuration, seeded noise."""
+    import numpy as np
+    from oracle import oracle as O
+    d = make_decoder(None, O.AmbiDec)
+    rng = np.random.default_rng(0)
+    x = (rng.random((8, NCH, FRAME), dtype=np.float32) * 2 - 1)
+    for i in range(8):
+        d.process(x[i], NCH)                       # warm-up (also past the filterbank transient)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for i in range(8):
+            d.process(x[i], NCH)
+        n += 8
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    dt = time.perf_counter() - t0
+    f, g, b = d.stageTimes()
+    return {"value": round(n / dt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n} consecutive 512-sample blocks of one order-7 64->64 instance, {dt:.1f} s on 1 core "
+                      f"(gcc -O3 -march=native, no BLAS; stage split afSTFT fwd/decode/afSTFT bwd = "
+                      f"{1e3 * f / (n + 8):.3f}/{1e3 * g / (n + 8):.3f}/{1e3 * b / (n + 8):.3f} ms per block)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("SAF_BENCH_INSTANCES", 32)), help="decoder instances per GPU")
+    ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("SAF_BENCH_FRAMES", 16)), help="consecutive blocks per instance per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from spatial_audio_framework_amd import api
+    from spatial_audio_framework_amd._lib import load
+    L = load()
+    L.saf_hip_set_device(dev.index)
+    api.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    nI, nF = args.instances, args.frames_per_call
+    decs = [make_decoder(api, api.AmbiDec) for _ in range(nI)]
+    batch = api.AmbiDecBatch(decs, nF)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    # two alternating input sets so consecutive steps do not re-read identical data
+    xs = [torch.rand(nI, nF, NCH, FRAME, device=dev, generator=g) * 2 - 1 for _ in range(2)]
+    y = torch.zeros(nI, nF, NCH, FRAME, device=dev)
+    st = (nF * NCH * FRAME, NCH * FRAME, FRAME)
+
+    def step(i):
+        batch.process_ptr(xs[i & 1].data_ptr(), st, y.data_ptr(), st, nF)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    L.saf_hip_profile_reset()
+    L.saf_hip_profile_enable(0 if args.no_profile else 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.saf_hip_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames_total = world * nI * nF * args.steps
+    value = frames_total / elapsed
+
+    if rank == 0:
+        roof = None
+        if not args.no_profile:
+            per = {}
+            for k in ALG_BYTES_PER_FRAME:
+                tot = C.c_double()
+                n = L.saf_hip_profile_read(k.encode(), C.byref(tot))
+                if n:
+                    per[k] = (tot.value / n, n)
+            if per:
+                dom = max(per, key=lambda k: per[k][0])
+                avg_ms, nl = per[dom]
+                frames_per_launch = nI * nF
+                traffic = None
+                tf = ROOT / "profiles" / "traffic_latest.json"
+                if tf.exists():
+                    try:
+                        traffic = json.loads(tf.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+                    except Exception:
+                        traffic = None
+                if dom == "band_gemm":
+                    ach = GEMM_FLOP_PER_FRAME * frames_per_launch / (avg_ms * 1e-3) / 1e12
+                    roof = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic}
+                else:
+                    ach = ALG_BYTES_PER_FRAME[dom] * frames_per_launch / (avg_ms * 1e-3) / 1e9
+                    roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
+                roof["avg_launch_ms"] = round(avg_ms, 5)
+                roof["launches"] = nl
+                roof["kernels_ms"] = {k: round(v[0], 5) for k, v in per.items()}
+                roof["path_hbm_frac"] = round(PATH_BYTES_PER_FRAME * (value / world) / 1e9 / HBM_PEAK_GBS, 4)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline()
+        line = {
+            "metric": "audio-frames/sec (512-sample, 128-ch, 7th-order ambi_dec)",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ambi_dec order 7: 64 SH in -> 64 loudspeakers out (SphCovering-64, SAD, maxrE, energy-preserving, N3D/ACN), "
+                                   "512-sample blocks, fs 48 kHz; batched device-resident entry point",
+                       "instances_per_gpu": nI, "frames_per_step_per_instance": nF, "frames_per_step_per_gpu": nI * nF,
+                       "parallelism": f"independent instances sharded over {world} GPU(s), no collective on the data path"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["speedup_vs_cpu_1core"] = round(value / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

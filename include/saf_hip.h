@@ -1,0 +1,234 @@
+/*
+ * saf_hip.h — C-ABI of libsaf_hip: the MI355X (gfx950) implementation of the SAF
+ * per-block rendering hot path.
+ *
+ * Every function below that carries a SAF name keeps the reference's signature,
+ * argument meaning and error behaviour, so a SAF caller links against this
+ * library instead of the reference objects for this path.
+ * The reference interface each entry replaces is cited as file:line relative to
+ * the SAF checkout.  Functions prefixed `saf_hip_` are additions: device-pointer
+ * and batched entry points (throughput needs many frames/instances per launch)
+ * and runtime control.  No torch / C++ types cross this boundary.
+ *
+ * Error behaviour: no return codes.  A process call with the wrong
+ * block size or an un-initialised codec zero-fills its outputs.  Violated
+ * preconditions and any HIP failure abort with a message — there is no CPU
+ * fallback anywhere in this library.
+ */
+#ifndef SAF_HIP_H_INCLUDED
+#define SAF_HIP_H_INCLUDED
+
+#ifdef __cplusplus
+# include <complex>
+typedef std::complex<float> float_complex;     /* framework/modules/saf_utilities/saf_utility_complex.h:34 */
+extern "C" {
+#else
+typedef float _Complex float_complex;          /* saf_utility_complex.h:70 */
+#endif
+
+#define SAF_API __attribute__((visibility("default")))
+
+/* ========================================================================== */
+/*                                 runtime                                    */
+/* ========================================================================== */
+/** Adopt a caller-owned hipStream_t (NULL: library-owned stream). All library work is enqueued on it. */
+SAF_API void  saf_hip_set_stream(void* hipStream);
+SAF_API void* saf_hip_get_stream(void);
+SAF_API void  saf_hip_synchronize(void);
+SAF_API int   saf_hip_device_count(void);
+SAF_API void  saf_hip_set_device(int dev);
+SAF_API const char* saf_hip_version(void);
+/** Per-kernel timing with HIP events recorded on the library stream around every kernel launch
+ *  ("afstft_analysis", "band_gemm", "afstft_synthesis", ...). read() synchronises, returns the number
+ *  of launches of `kernelName` since reset() and their summed duration. */
+SAF_API void saf_hip_profile_enable(int on);
+SAF_API void saf_hip_profile_reset(void);
+SAF_API int  saf_hip_profile_read(const char* kernelName, double* total_ms);
+
+/* ========================================================================== */
+/*      afSTFT  (framework/resources/afSTFT/afSTFTlib.h:85-278)               */
+/* ========================================================================== */
+typedef enum {                      /* afSTFTlib.h:79-83 */
+    AFSTFT_BANDS_CH_TIME,
+    AFSTFT_TIME_CH_BANDS
+} AFSTFT_FDDATA_FORMAT;
+
+/** afSTFTlib.h:107 / afSTFTlib.c:142. This build implements hopsize 128 (what every operator uses). */
+SAF_API void afSTFT_create(void** const phSTFT, int nCHin, int nCHout, int hopsize, int lowDelayMode, int hybridmode, AFSTFT_FDDATA_FORMAT format);
+SAF_API void afSTFT_destroy(void** const phSTFT);                                                         /* afSTFTlib.h:120 */
+SAF_API void afSTFT_forward(void* const hSTFT, float** dataTD, int framesize, float_complex*** dataFD);   /* afSTFTlib.h:130 */
+SAF_API void afSTFT_forward_knownDimensions(void* const hSTFT, float** dataTD, int framesize, int dataFD_nCH, int dataFD_nHops, float_complex*** dataFD); /* afSTFTlib.h:149 */
+SAF_API void afSTFT_forward_flat(void* const hSTFT, float* dataTD, int framesize, float_complex* dataFD); /* afSTFTlib.h:164 */
+SAF_API void afSTFT_backward(void* const hSTFT, float_complex*** dataFD, int framesize, float** dataTD);  /* afSTFTlib.h:177 */
+SAF_API void afSTFT_backward_knownDimensions(void* const hSTFT, float_complex*** dataFD, int framesize, int dataFD_nCH, int dataFD_nHops, float** dataTD); /* afSTFTlib.h:196 */
+SAF_API void afSTFT_backward_flat(void* const hSTFT, float_complex* dataFD, int framesize, float* dataTD); /* afSTFTlib.h:211 */
+SAF_API void afSTFT_channelChange(void* const hSTFT, int new_nCHin, int new_nCHout);                      /* afSTFTlib.h:224 */
+SAF_API void afSTFT_clearBuffers(void* const hSTFT);                                                      /* afSTFTlib.h:229 */
+SAF_API int  afSTFT_getNBands(void* const hSTFT);                                                         /* afSTFTlib.h:232 */
+SAF_API int  afSTFT_getProcDelay(void* const hSTFT);                                                      /* afSTFTlib.h:247 */
+SAF_API void afSTFT_getCentreFreqs(void* const hSTFT, float fs, int nBands, float* freqVector);           /* afSTFTlib.h:250 */
+SAF_API void afSTFT_FIRtoFilterbankCoeffs(float* hIR, int N_dirs, int nCH, int ir_len, int hopSize, int LDmode, int hybridmode, float_complex* hFB); /* afSTFTlib.h:269 */
+
+/** Device-pointer transform of `nHops` hops for all channels of the handle.
+ *  d_td[ch*td_ch_stride + t]  (floats, 16-byte aligned, strides multiple of 4);
+ *  d_fd[band*fd_band_stride + ch*fd_ch_stride + hop] (complex). State carries over between calls
+ *  exactly like consecutive afSTFT_forward calls. */
+SAF_API void saf_hip_afSTFT_forward_dev(void* const hSTFT, const float* d_td, long long td_ch_stride, int nHops,
+                                        float_complex* d_fd, long long fd_band_stride, long long fd_ch_stride);
+SAF_API void saf_hip_afSTFT_backward_dev(void* const hSTFT, const float_complex* d_fd, long long fd_band_stride, long long fd_ch_stride,
+                                         int nHops, float* d_td, long long td_ch_stride);
+
+/* ========================================================================== */
+/*      spherical harmonics / HOA (saf_sh.h, saf_hoa.h)                       */
+/* ========================================================================== */
+SAF_API void getSHreal(int order, float* dirs_rad, int nDirs, float* Y);        /* saf_sh.h:176 / saf_sh.c:190 */
+SAF_API void getSHreal_recur(int order, float* dirs_rad, int nDirs, float* Y);  /* saf_sh.h:211 / saf_sh.c:255 */
+SAF_API void getRSH(int order, float* dirs_deg, int nDirs, float* Y);           /* saf_hoa.h:293 / saf_hoa.c:118 */
+SAF_API void getRSH_recur(int order, float* dirs_deg, int nDirs, float* Y);     /* saf_hoa.h:328 / saf_hoa.c:152 */
+/** Same as getRSH_recur but with device pointers (dirs [nDirs][2] degrees, Y [nSH][nDirs]). */
+SAF_API void saf_hip_getRSH_recur_dev(int order, const float* d_dirs_deg, int nDirs, float* d_Y);
+
+typedef enum { HOA_CH_ORDER_ACN, HOA_CH_ORDER_FUMA } HOA_CH_ORDER;              /* saf_hoa.h:183-188 */
+typedef enum { HOA_NORM_N3D, HOA_NORM_SN3D, HOA_NORM_FUMA } HOA_NORM;           /* saf_hoa.h:205-211 */
+SAF_API void convertHOAChannelConvention(float* insig, int order, int signalLength, HOA_CH_ORDER inConvention, HOA_CH_ORDER outConvention); /* saf_hoa.h:237 */
+SAF_API void convertHOANormConvention(float* insig, int order, int signalLength, HOA_NORM inConvention, HOA_NORM outConvention);           /* saf_hoa.h:262 */
+SAF_API void getMaxREweights(int order, int diagMtxFlag, float* a_n);          /* saf_hoa.h:363 / saf_hoa.c:235 */
+
+typedef enum {                                                                  /* saf_hoa.h:61-111 */
+    LOUDSPEAKER_DECODER_DEFAULT,
+    LOUDSPEAKER_DECODER_SAD,
+    LOUDSPEAKER_DECODER_MMD,
+    LOUDSPEAKER_DECODER_EPAD,
+    LOUDSPEAKER_DECODER_ALLRAD
+} LOUDSPEAKER_AMBI_DECODER_METHODS;
+SAF_API void getLoudspeakerDecoderMtx(float* ls_dirs_deg, int nLS, LOUDSPEAKER_AMBI_DECODER_METHODS method, int order, int enableMaxReWeighting, float* decMtx); /* saf_hoa.h:413 / saf_hoa.c:326 */
+
+/* ========================================================================== */
+/*      VBAP (saf_vbap.h:73-450)                                              */
+/* ========================================================================== */
+SAF_API void generateVBAPgainTable3D_srcs(float* src_dirs_deg, int S, float* ls_dirs_deg, int L, int omitLargeTriangles, int enableDummies, float spread, float** gtable, int* N_gtable, int* nTriangles); /* saf_vbap.h:73 */
+SAF_API void generateVBAPgainTable3D(float* ls_dirs_deg, int L, int az_res_deg, int el_res_deg, int omitLargeTriangles, int enableDummies, float spread, float** gtable, int* N_gtable, int* nTriangles);   /* saf_vbap.h:129 */
+SAF_API void compressVBAPgainTable3D(float* vbap_gtable, int nTable, int nDirs, float* vbap_gtableComp, int* vbap_gtableIdx); /* saf_vbap.h:174 */
+SAF_API void VBAPgainTable2InterpTable(float* vbap_gtable, int nTable, int nDirs);                                           /* saf_vbap.h:192 */
+SAF_API void findLsTriplets(float* ls_dirs_deg, int L, int omitLargeTriangles, float** out_vertices, int* numOutVertices, int** out_faces, int* numOutFaces); /* saf_vbap.h:328 */
+SAF_API void invertLsMtx3D(float* U_spkr, int* ls_groups, int N_group, float** layoutInvMtx);                                /* saf_vbap.h:348 */
+SAF_API void vbap3D(float* src_dirs, int src_num, int ls_num, int* ls_groups, int nFaces, float spread, float* layoutInvMtx, float** GainMtx); /* saf_vbap.h:393 */
+
+/* ========================================================================== */
+/*      shared operator enums (examples/include/_common.h)                    */
+/* ========================================================================== */
+typedef enum { CH_ACN = 1, CH_FUMA } CH_ORDER;                                   /* _common.h:57-61 */
+typedef enum { NORM_N3D = 1, NORM_SN3D, NORM_FUMA } NORM_TYPES;                  /* _common.h:70-75 */
+typedef enum { CODEC_STATUS_INITIALISED = 0, CODEC_STATUS_NOT_INITIALISED, CODEC_STATUS_INITIALISING } CODEC_STATUS; /* _common.h:199-207 */
+typedef enum { PROC_STATUS_ONGOING = 0, PROC_STATUS_NOT_ONGOING } PROC_STATUS;   /* _common.h:215-220 */
+typedef enum { MIC_PRESET_IDEAL = 1, MIC_PRESET_ZYLIA, MIC_PRESET_EIGENMIKE32, MIC_PRESET_DTU_MIC } MIC_PRESETS;   /* _common.h:78-84 */
+typedef enum {                                                                   /* _common.h:88-119 */
+    LOUDSPEAKER_ARRAY_PRESET_DEFAULT = 1, LOUDSPEAKER_ARRAY_PRESET_STEREO, LOUDSPEAKER_ARRAY_PRESET_5PX, LOUDSPEAKER_ARRAY_PRESET_7PX,
+    LOUDSPEAKER_ARRAY_PRESET_8PX, LOUDSPEAKER_ARRAY_PRESET_9PX, LOUDSPEAKER_ARRAY_PRESET_10PX, LOUDSPEAKER_ARRAY_PRESET_11PX,
+    LOUDSPEAKER_ARRAY_PRESET_11PX_7_4, LOUDSPEAKER_ARRAY_PRESET_13PX, LOUDSPEAKER_ARRAY_PRESET_22PX, LOUDSPEAKER_ARRAY_PRESET_22P2_9_10_3,
+    LOUDSPEAKER_ARRAY_PRESET_AALTO_MCC, LOUDSPEAKER_ARRAY_PRESET_AALTO_MCC_SUBSET, LOUDSPEAKER_ARRAY_PRESET_AALTO_APAJA,
+    LOUDSPEAKER_ARRAY_PRESET_AALTO_LR, LOUDSPEAKER_ARRAY_PRESET_DTU_AVIL, LOUDSPEAKER_ARRAY_PRESET_ZYLIA_LAB,
+    LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_4, LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_12, LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_24,
+    LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_36, LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_48, LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_60,
+    LOUDSPEAKER_ARRAY_PRESET_SPH_COV_9, LOUDSPEAKER_ARRAY_PRESET_SPH_COV_16, LOUDSPEAKER_ARRAY_PRESET_SPH_COV_25,
+    LOUDSPEAKER_ARRAY_PRESET_SPH_COV_49, LOUDSPEAKER_ARRAY_PRESET_SPH_COV_64
+} LOUDSPEAKER_ARRAY_PRESETS;
+typedef enum {                                                                   /* _common.h:123-155 */
+    SOURCE_CONFIG_PRESET_DEFAULT = 1, SOURCE_CONFIG_PRESET_MONO, SOURCE_CONFIG_PRESET_STEREO, SOURCE_CONFIG_PRESET_5PX, SOURCE_CONFIG_PRESET_7PX,
+    SOURCE_CONFIG_PRESET_8PX, SOURCE_CONFIG_PRESET_9PX, SOURCE_CONFIG_PRESET_10PX, SOURCE_CONFIG_PRESET_11PX, SOURCE_CONFIG_PRESET_11PX_7_4,
+    SOURCE_CONFIG_PRESET_13PX, SOURCE_CONFIG_PRESET_22PX, SOURCE_CONFIG_PRESET_22P2_9_10_3, SOURCE_CONFIG_PRESET_AALTO_MCC,
+    SOURCE_CONFIG_PRESET_AALTO_MCC_SUBSET, SOURCE_CONFIG_PRESET_AALTO_APAJA, SOURCE_CONFIG_PRESET_AALTO_LR, SOURCE_CONFIG_PRESET_DTU_AVIL,
+    SOURCE_CONFIG_PRESET_ZYLIA_LAB, SOURCE_CONFIG_PRESET_T_DESIGN_4, SOURCE_CONFIG_PRESET_T_DESIGN_12, SOURCE_CONFIG_PRESET_T_DESIGN_24,
+    SOURCE_CONFIG_PRESET_T_DESIGN_36, SOURCE_CONFIG_PRESET_T_DESIGN_48, SOURCE_CONFIG_PRESET_T_DESIGN_60, SOURCE_CONFIG_PRESET_SPH_COV_9,
+    SOURCE_CONFIG_PRESET_SPH_COV_16, SOURCE_CONFIG_PRESET_SPH_COV_25, SOURCE_CONFIG_PRESET_SPH_COV_49, SOURCE_CONFIG_PRESET_SPH_COV_64
+} SOURCE_CONFIG_PRESETS;
+#define PROGRESSBARTEXT_CHAR_LENGTH ( 256 )                                      /* _common.h:225 */
+#define MAX_NUM_CHANNELS ( 64 )                                                  /* _common.h:228 */
+#define MAX_SH_ORDER ( 7 )                                                       /* _common.h:50 */
+
+/* ========================================================================== */
+/*      ambi_dec (examples/include/ambi_dec.h:114-520)                        */
+/* ========================================================================== */
+typedef enum { DECODING_METHOD_SAD = 1, DECODING_METHOD_MMD, DECODING_METHOD_EPAD, DECODING_METHOD_ALLRAD } AMBI_DEC_DECODING_METHODS; /* ambi_dec.h:73-78 */
+typedef enum { AMPLITUDE_PRESERVING = 1, ENERGY_PRESERVING } AMBI_DEC_DIFFUSE_FIELD_EQ_APPROACH;                                  /* ambi_dec.h:92-95 */
+
+/** The reference fixes the block size at compile time (-DAMBI_DEC_FRAME_SIZE, ambi_dec_internal.h:61-67, default 128).
+ *  Here it is a process-wide setting read by ambi_dec_create; must be a multiple of 128. */
+SAF_API void saf_hip_ambi_dec_setFrameSize(int frameSize);
+
+SAF_API void ambi_dec_create(void** const phAmbi);                               /* ambi_dec.h:114 */
+SAF_API void ambi_dec_destroy(void** const phAmbi);                              /* ambi_dec.h:121 */
+SAF_API void ambi_dec_init(void* const hAmbi, int samplerate);                   /* ambi_dec.h:131 */
+SAF_API void ambi_dec_initCodec(void* const hAmbi);                              /* ambi_dec.h:149 */
+SAF_API void ambi_dec_process(void* const hAmbi, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* ambi_dec.h:161 */
+SAF_API void ambi_dec_refreshSettings(void* const hAmbi);                        /* ambi_dec.h:177 */
+SAF_API void ambi_dec_setMasterDecOrder(void* const hAmbi, int newValue);        /* ambi_dec.h:188 */
+SAF_API void ambi_dec_setDecOrder(void* const hAmbi, int newValue, int bandIdx); /* ambi_dec.h:199 */
+SAF_API void ambi_dec_setDecOrderAllBands(void* const hAmbi, int newValue);      /* ambi_dec.h:209 */
+SAF_API void ambi_dec_setLoudspeakerAzi_deg(void* const hAmbi, int index, float newAzi_deg);   /* ambi_dec.h:218 */
+SAF_API void ambi_dec_setLoudspeakerElev_deg(void* const hAmbi, int index, float newElev_deg); /* ambi_dec.h:229 */
+SAF_API void ambi_dec_setNumLoudspeakers(void* const hAmbi, int new_nLoudspeakers);            /* ambi_dec.h:236 */
+SAF_API void ambi_dec_setBinauraliseLSflag(void* const hAmbi, int newState);     /* ambi_dec.h:246 */
+SAF_API void ambi_dec_setUseDefaultHRIRsflag(void* const hAmbi, int newState);   /* ambi_dec.h:259 */
+SAF_API void ambi_dec_setSofaFilePath(void* const hAmbi, const char* path);      /* ambi_dec.h:272 */
+SAF_API void ambi_dec_setEnableHRIRsPreProc(void* const hAmbi, int newState);    /* ambi_dec.h:275 */
+SAF_API void ambi_dec_setSourcePreset(void* const hAmbi, int newPresetID);       /* ambi_dec.h:287 */
+SAF_API void ambi_dec_setOutputConfigPreset(void* const hAmbi, int newPresetID); /* ambi_dec.h:295 */
+SAF_API void ambi_dec_setChOrder(void* const hAmbi, int newOrder);               /* ambi_dec.h:301 */
+SAF_API void ambi_dec_setNormType(void* const hAmbi, int newType);               /* ambi_dec.h:307 */
+SAF_API void ambi_dec_setDecMethod(void* const hAmbi, int index, int newID);     /* ambi_dec.h:318 */
+SAF_API void ambi_dec_setDecEnableMaxrE(void* const hAmbi, int index, int newID);/* ambi_dec.h:328 */
+SAF_API void ambi_dec_setDecNormType(void* const hAmbi, int index, int newID);   /* ambi_dec.h:343 */
+SAF_API void ambi_dec_setTransitionFreq(void* const hAmbi, float newValue);      /* ambi_dec.h:352 */
+SAF_API int  ambi_dec_getFrameSize(void);                                        /* ambi_dec.h:363 */
+SAF_API CODEC_STATUS ambi_dec_getCodecStatus(void* const hAmbi);                 /* ambi_dec.h:366 */
+SAF_API float ambi_dec_getProgressBar0_1(void* const hAmbi);                     /* ambi_dec.h:373 */
+SAF_API void ambi_dec_getProgressBarText(void* const hAmbi, char* text);         /* ambi_dec.h:381 */
+SAF_API int  ambi_dec_getMasterDecOrder(void* const hAmbi);                      /* ambi_dec.h:384 */
+SAF_API int  ambi_dec_getDecOrder(void* const hAmbi, int bandIdx);               /* ambi_dec.h:390 */
+SAF_API int  ambi_dec_getDecOrderAllBands(void* const hAmbi);                    /* ambi_dec.h:393 */
+SAF_API void ambi_dec_getDecOrderHandle(void* const hAmbi, float** pX_vector, int** pY_values, int* pNpoints); /* ambi_dec.h:403 */
+SAF_API int  ambi_dec_getNumberOfBands(void);                                    /* ambi_dec.h:409 */
+SAF_API float ambi_dec_getLoudspeakerAzi_deg(void* const hAmbi, int index);      /* ambi_dec.h:412 */
+SAF_API float ambi_dec_getLoudspeakerElev_deg(void* const hAmbi, int index);     /* ambi_dec.h:415 */
+SAF_API int  ambi_dec_getNumLoudspeakers(void* const hAmbi);                     /* ambi_dec.h:418 */
+SAF_API int  ambi_dec_getMaxNumLoudspeakers(void);                               /* ambi_dec.h:421 */
+SAF_API int  ambi_dec_getNSHrequired(void* const hAmbi);                         /* ambi_dec.h:427 */
+SAF_API int  ambi_dec_getBinauraliseLSflag(void* const hAmbi);                   /* ambi_dec.h:434 */
+SAF_API int  ambi_dec_getUseDefaultHRIRsflag(void* const hAmbi);                 /* ambi_dec.h:444 */
+SAF_API char* ambi_dec_getSofaFilePath(void* const hAmbi);                       /* ambi_dec.h:453 */
+SAF_API int  ambi_dec_getEnableHRIRsPreProc(void* const hAmbi);                  /* ambi_dec.h:459 */
+SAF_API int  ambi_dec_getChOrder(void* const hAmbi);                             /* ambi_dec.h:466 */
+SAF_API int  ambi_dec_getNormType(void* const hAmbi);                            /* ambi_dec.h:473 */
+SAF_API int  ambi_dec_getDecMethod(void* const hAmbi, int index);                /* ambi_dec.h:479 */
+SAF_API int  ambi_dec_getDecEnableMaxrE(void* const hAmbi, int index);           /* ambi_dec.h:489 */
+SAF_API int  ambi_dec_getDecNormType(void* const hAmbi, int index);              /* ambi_dec.h:502 */
+SAF_API float ambi_dec_getTransitionFreq(void* const hAmbi);                     /* ambi_dec.h:508 */
+SAF_API int  ambi_dec_getHRIRsamplerate(void* const hAmbi);                      /* ambi_dec.h:511 */
+SAF_API int  ambi_dec_getDAWsamplerate(void* const hAmbi);                       /* ambi_dec.h:514 */
+SAF_API int  ambi_dec_getProcessingDelay(void);                                  /* ambi_dec.h:520 */
+
+/** Read-back of the designed decoder (what ambi_dec_codecPars holds, ambi_dec_internal.h:88-96): [nLS x (order+1)^2]. */
+SAF_API void saf_hip_ambi_dec_getDecoderMtx(void* const hAmbi, int decIdx, int order, int maxrE, float* out);
+SAF_API float saf_hip_ambi_dec_getDecoderNorm(void* const hAmbi, int decIdx, int order, int ampOrEnergy);
+
+/* ---- batched, device-resident entry point (throughput path) ----
+ * A batch groups nInst initialised ambi_dec handles with the same block size, master order and
+ * loudspeaker count (decoders may differ per instance).  One call processes nFrames consecutive
+ * blocks of every instance; filterbank state carries over between calls exactly as between
+ * consecutive ambi_dec_process calls.  Sample addressing (floats):
+ *     x[inst*inst_stride + frame*frame_stride + ch*ch_stride + n],  n < frameSize
+ * Pointers are device pointers, 16-byte aligned, strides multiples of 4.  Work is enqueued on the
+ * library stream and NOT synchronised. */
+SAF_API void* saf_hip_ambi_dec_batch_create(void* const* hAmbis, int nInst, int maxFramesPerCall);
+SAF_API void  saf_hip_ambi_dec_batch_destroy(void** const phBatch);
+SAF_API void  saf_hip_ambi_dec_batch_clear(void* const hBatch);
+SAF_API void  saf_hip_ambi_dec_batch_process(void* const hBatch,
+                                             const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride,
+                                             float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride,
+                                             int nFrames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAF_HIP_H_INCLUDED */

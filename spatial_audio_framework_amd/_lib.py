@@ -1,0 +1,126 @@
+"""ctypes loader for libsaf_hip.so — the only compute path of this package.
+
+There is deliberately no fallback: if the HIP library is missing the import of
+any compute entry point fails loudly.
+"""
+import ctypes as C
+import os
+import re
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+SO = PKG / "libsaf_hip.so"
+HEADER = PKG.parent / "include" / "saf_hip.h"
+_lib = None
+
+
+class SafHipMissing(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Names of every function include/saf_hip.h declares (lines tagged SAF_API)."""
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"SAF_API\s+[\w\s\*]+?\b(\w+)\s*\(", text)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not SO.exists():
+        raise SafHipMissing(
+            f"{SO} not found. Build it with `python -m spatial_audio_framework_amd.build` "
+            "(hipcc, --offload-arch=gfx950). This package has no CPU fallback.")
+    L = C.CDLL(str(SO), mode=C.RTLD_GLOBAL)
+    vp, ci, cf, cll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+    fp = C.POINTER(C.c_float)
+    ip = C.POINTER(C.c_int)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("saf_hip_set_stream", None, vp)
+    sig("saf_hip_get_stream", vp)
+    sig("saf_hip_synchronize", None)
+    sig("saf_hip_device_count", ci)
+    sig("saf_hip_set_device", None, ci)
+    sig("saf_hip_version", C.c_char_p)
+    sig("saf_hip_profile_enable", None, ci)
+    sig("saf_hip_profile_reset", None)
+    sig("saf_hip_profile_read", ci, C.c_char_p, C.POINTER(C.c_double))
+    # afSTFT
+    sig("afSTFT_create", None, C.POINTER(vp), ci, ci, ci, ci, ci, ci)
+    sig("afSTFT_destroy", None, C.POINTER(vp))
+    sig("afSTFT_forward_flat", None, vp, fp, ci, vp)
+    sig("afSTFT_backward_flat", None, vp, vp, ci, fp)
+    sig("afSTFT_forward_knownDimensions", None, vp, C.POINTER(fp), ci, ci, ci, vp)
+    sig("afSTFT_backward_knownDimensions", None, vp, vp, ci, ci, ci, C.POINTER(fp))
+    sig("afSTFT_forward", None, vp, C.POINTER(fp), ci, vp)
+    sig("afSTFT_backward", None, vp, vp, ci, C.POINTER(fp))
+    sig("afSTFT_channelChange", None, vp, ci, ci)
+    sig("afSTFT_clearBuffers", None, vp)
+    sig("afSTFT_getNBands", ci, vp)
+    sig("afSTFT_getProcDelay", ci, vp)
+    sig("afSTFT_getCentreFreqs", None, vp, cf, ci, fp)
+    sig("afSTFT_FIRtoFilterbankCoeffs", None, fp, ci, ci, ci, ci, ci, ci, vp)
+    sig("saf_hip_afSTFT_forward_dev", None, vp, vp, cll, ci, vp, cll, cll)
+    sig("saf_hip_afSTFT_backward_dev", None, vp, vp, cll, cll, ci, vp, cll)
+    # SH / HOA
+    for n in ("getSHreal", "getSHreal_recur", "getRSH", "getRSH_recur"):
+        sig(n, None, ci, fp, ci, fp)
+    sig("saf_hip_getRSH_recur_dev", None, ci, vp, ci, vp)
+    sig("getMaxREweights", None, ci, ci, fp)
+    sig("convertHOAChannelConvention", None, fp, ci, ci, ci, ci)
+    sig("convertHOANormConvention", None, fp, ci, ci, ci, ci)
+    sig("getLoudspeakerDecoderMtx", None, fp, ci, ci, ci, ci, fp)
+    # VBAP
+    sig("findLsTriplets", None, fp, ci, ci, C.POINTER(fp), ip, C.POINTER(ip), ip)
+    sig("invertLsMtx3D", None, fp, ip, ci, C.POINTER(fp))
+    sig("vbap3D", None, fp, ci, ci, ip, ci, cf, fp, C.POINTER(fp))
+    sig("generateVBAPgainTable3D_srcs", None, fp, ci, fp, ci, ci, ci, cf, C.POINTER(fp), ip, ip)
+    sig("generateVBAPgainTable3D", None, fp, ci, ci, ci, ci, ci, cf, C.POINTER(fp), ip, ip)
+    sig("compressVBAPgainTable3D", None, fp, ci, ci, fp, ip)
+    sig("VBAPgainTable2InterpTable", None, fp, ci, ci)
+    # ambi_dec
+    sig("saf_hip_ambi_dec_setFrameSize", None, ci)
+    sig("ambi_dec_create", None, C.POINTER(vp))
+    sig("ambi_dec_destroy", None, C.POINTER(vp))
+    sig("ambi_dec_init", None, vp, ci)
+    sig("ambi_dec_initCodec", None, vp)
+    sig("ambi_dec_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("ambi_dec_refreshSettings", None, vp)
+    for n in ("setMasterDecOrder", "setDecOrderAllBands", "setNumLoudspeakers", "setBinauraliseLSflag", "setUseDefaultHRIRsflag",
+              "setEnableHRIRsPreProc", "setSourcePreset", "setOutputConfigPreset", "setChOrder", "setNormType"):
+        sig("ambi_dec_" + n, None, vp, ci)
+    for n in ("setDecOrder", "setDecMethod", "setDecEnableMaxrE", "setDecNormType"):
+        sig("ambi_dec_" + n, None, vp, ci, ci)
+    sig("ambi_dec_setLoudspeakerAzi_deg", None, vp, ci, cf)
+    sig("ambi_dec_setLoudspeakerElev_deg", None, vp, ci, cf)
+    sig("ambi_dec_setSofaFilePath", None, vp, C.c_char_p)
+    sig("ambi_dec_setTransitionFreq", None, vp, cf)
+    for n in ("getFrameSize", "getNumberOfBands", "getMaxNumLoudspeakers", "getProcessingDelay"):
+        sig("ambi_dec_" + n, ci)
+    for n in ("getCodecStatus", "getMasterDecOrder", "getDecOrderAllBands", "getNumLoudspeakers", "getNSHrequired", "getBinauraliseLSflag",
+              "getUseDefaultHRIRsflag", "getEnableHRIRsPreProc", "getChOrder", "getNormType", "getHRIRsamplerate", "getDAWsamplerate"):
+        sig("ambi_dec_" + n, ci, vp)
+    for n in ("getDecOrder", "getDecMethod", "getDecEnableMaxrE", "getDecNormType"):
+        sig("ambi_dec_" + n, ci, vp, ci)
+    sig("ambi_dec_getProgressBar0_1", cf, vp)
+    sig("ambi_dec_getProgressBarText", None, vp, C.c_char_p)
+    sig("ambi_dec_getDecOrderHandle", None, vp, C.POINTER(fp), C.POINTER(ip), ip)
+    sig("ambi_dec_getLoudspeakerAzi_deg", cf, vp, ci)
+    sig("ambi_dec_getLoudspeakerElev_deg", cf, vp, ci)
+    sig("ambi_dec_getSofaFilePath", C.c_char_p, vp)
+    sig("ambi_dec_getTransitionFreq", cf, vp)
+    sig("saf_hip_ambi_dec_getDecoderMtx", None, vp, ci, ci, ci, fp)
+    sig("saf_hip_ambi_dec_getDecoderNorm", cf, vp, ci, ci, ci)
+    sig("saf_hip_ambi_dec_batch_create", vp, C.POINTER(vp), ci, ci)
+    sig("saf_hip_ambi_dec_batch_destroy", None, C.POINTER(vp))
+    sig("saf_hip_ambi_dec_batch_clear", None, vp)
+    sig("saf_hip_ambi_dec_batch_process", None, vp, vp, cll, cll, cll, vp, cll, cll, cll, ci)
+    _lib = L
+    return L

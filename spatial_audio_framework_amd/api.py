@@ -1,0 +1,263 @@
+"""Python mirror of the SAF operator / framework interface for the hot path,
+implemented by calling libsaf_hip.so through its C-ABI (include/saf_hip.h).
+
+Names, argument meaning and error behaviour follow the reference headers
+(examples/include/ambi_dec.h, framework/resources/afSTFT/afSTFTlib.h,
+framework/modules/saf_hoa/saf_hoa.h, saf_sh.h, saf_vbap.h).  This layer only
+marshals numpy arrays / device pointers; all arithmetic happens in the library.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import load
+
+vp = C.c_void_p
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+
+# enums (include/saf_hip.h)
+AFSTFT_BANDS_CH_TIME, AFSTFT_TIME_CH_BANDS = 0, 1
+CH_ACN, CH_FUMA = 1, 2
+NORM_N3D, NORM_SN3D, NORM_FUMA = 1, 2, 3
+DECODING_METHOD_SAD, DECODING_METHOD_MMD, DECODING_METHOD_EPAD, DECODING_METHOD_ALLRAD = 1, 2, 3, 4
+LOUDSPEAKER_DECODER_SAD, LOUDSPEAKER_DECODER_MMD, LOUDSPEAKER_DECODER_EPAD, LOUDSPEAKER_DECODER_ALLRAD = 1, 2, 3, 4
+AMPLITUDE_PRESERVING, ENERGY_PRESERVING = 1, 2
+CODEC_STATUS_INITIALISED, CODEC_STATUS_NOT_INITIALISED, CODEC_STATUS_INITIALISING = 0, 1, 2
+LOUDSPEAKER_ARRAY_PRESET_22PX = 11
+LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_24 = 21
+LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_60 = 24
+LOUDSPEAKER_ARRAY_PRESET_SPH_COV_49 = 28
+LOUDSPEAKER_ARRAY_PRESET_SPH_COV_64 = 29
+
+
+def _f(a):
+    return a.ctypes.data_as(fp)
+
+
+def _rows(a):
+    arr = (fp * a.shape[0])()
+    for i in range(a.shape[0]):
+        arr[i] = a[i].ctypes.data_as(fp)
+    return arr
+
+
+def set_stream(ptr):
+    load().saf_hip_set_stream(vp(ptr))
+
+
+def synchronize():
+    load().saf_hip_synchronize()
+
+
+# ---------------------------------------------------------------- afSTFT
+class AfSTFT:
+    def __init__(self, nCHin, nCHout, hopsize=128, lowDelay=0, hybrid=1, fmt=AFSTFT_BANDS_CH_TIME):
+        self.L = load()
+        self.h = vp()
+        self.nCHin, self.nCHout, self.hop, self.fmt = nCHin, nCHout, hopsize, fmt
+        self.L.afSTFT_create(C.byref(self.h), nCHin, nCHout, hopsize, lowDelay, hybrid, fmt)
+        self.nBands = self.L.afSTFT_getNBands(self.h)
+        self.delay = self.L.afSTFT_getProcDelay(self.h)
+
+    def forward(self, x):
+        """x [nCHin][framesize] -> [nBands][nCHin][nHops] (afSTFT_forward_flat)."""
+        x = np.ascontiguousarray(x, np.float32)
+        nH = x.shape[1] // self.hop
+        shape = (self.nBands, self.nCHin, nH) if self.fmt == AFSTFT_BANDS_CH_TIME else (nH, self.nCHin, self.nBands)
+        out = np.zeros(shape, np.complex64)
+        self.L.afSTFT_forward_flat(self.h, _f(x), x.shape[1], out.ctypes.data_as(vp))
+        return out
+
+    def forward_knownDimensions(self, x, nCH_alloc, nHops_alloc):
+        """Mimics a caller that owns a malloc3d [nBands][nCH_alloc][nHops_alloc] buffer."""
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.zeros((self.nBands, nCH_alloc, nHops_alloc), np.complex64)
+        # build the pointer tables of malloc3d so &dataFD[0][0][0] is the flat payload
+        rows2 = (vp * (self.nBands * nCH_alloc))()
+        base = out.ctypes.data
+        for i in range(self.nBands * nCH_alloc):
+            rows2[i] = base + i * nHops_alloc * 8
+        rows1 = (vp * self.nBands)()
+        for b in range(self.nBands):
+            rows1[b] = C.addressof(rows2) + b * nCH_alloc * C.sizeof(vp)
+        self.L.afSTFT_forward_knownDimensions(self.h, _rows(x), x.shape[1], nCH_alloc, nHops_alloc, C.cast(rows1, vp))
+        return out
+
+    def backward(self, X):
+        X = np.ascontiguousarray(X, np.complex64)
+        nH = X.shape[2] if self.fmt == AFSTFT_BANDS_CH_TIME else X.shape[0]
+        out = np.zeros((self.nCHout, nH * self.hop), np.float32)
+        self.L.afSTFT_backward_flat(self.h, X.ctypes.data_as(vp), nH * self.hop, _f(out))
+        return out
+
+    def channelChange(self, nin, nout):
+        self.L.afSTFT_channelChange(self.h, nin, nout)
+        self.nCHin, self.nCHout = nin, nout
+
+    def clearBuffers(self):
+        self.L.afSTFT_clearBuffers(self.h)
+
+    def centreFreqs(self, fs):
+        f = np.zeros(self.nBands, np.float32)
+        self.L.afSTFT_getCentreFreqs(self.h, C.c_float(fs), self.nBands, _f(f))
+        return f
+
+    def forward_dev(self, d_td_ptr, td_ch_stride, nHops, d_fd_ptr, fd_band_stride, fd_ch_stride):
+        self.L.saf_hip_afSTFT_forward_dev(self.h, vp(d_td_ptr), td_ch_stride, nHops, vp(d_fd_ptr), fd_band_stride, fd_ch_stride)
+
+    def backward_dev(self, d_fd_ptr, fd_band_stride, fd_ch_stride, nHops, d_td_ptr, td_ch_stride):
+        self.L.saf_hip_afSTFT_backward_dev(self.h, vp(d_fd_ptr), fd_band_stride, fd_ch_stride, nHops, vp(d_td_ptr), td_ch_stride)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.afSTFT_destroy(C.byref(self.h))
+
+
+def afSTFT_getCentreFreqs_nullHandle(fs):
+    f = np.zeros(133, np.float32)
+    load().afSTFT_getCentreFreqs(None, C.c_float(fs), 133, _f(f))
+    return f
+
+
+def afSTFT_FIRtoFilterbankCoeffs(hIR, hop=128, LD=0, hybrid=1):
+    hIR = np.ascontiguousarray(hIR, np.float32)
+    nd, nch, Lh = hIR.shape
+    out = np.zeros((hop + (5 if hybrid else 1), nch, nd), np.complex64)
+    load().afSTFT_FIRtoFilterbankCoeffs(_f(hIR), nd, nch, Lh, hop, LD, hybrid, out.ctypes.data_as(vp))
+    return out
+
+
+# ---------------------------------------------------------------- SH / HOA / VBAP
+def _sh(name, order, dirs):
+    d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 2)
+    Y = np.zeros(((order + 1) ** 2, d.shape[0]), np.float32)
+    getattr(load(), name)(order, _f(d), d.shape[0], _f(Y))
+    return Y
+
+
+def getSHreal(order, dirs_rad): return _sh("getSHreal", order, dirs_rad)
+def getSHreal_recur(order, dirs_rad): return _sh("getSHreal_recur", order, dirs_rad)
+def getRSH(order, dirs_deg): return _sh("getRSH", order, dirs_deg)
+def getRSH_recur(order, dirs_deg): return _sh("getRSH_recur", order, dirs_deg)
+
+
+def getMaxREweights(order, diag=False):
+    n = (order + 1) ** 2
+    a = np.zeros((n, n) if diag else n, np.float32)
+    load().getMaxREweights(order, int(diag), _f(a))
+    return a
+
+
+def getLoudspeakerDecoderMtx(ls_dirs_deg, method, order, maxrE=0):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    M = np.zeros((d.shape[0], (order + 1) ** 2), np.float32)
+    load().getLoudspeakerDecoderMtx(_f(d), d.shape[0], method, order, maxrE, _f(M))
+    return M
+
+
+def _take(ptr, shape, ctype=np.float32):
+    """Copy a malloc'd out-param into numpy and free it (caller-frees convention of the reference)."""
+    n = int(np.prod(shape))
+    a = np.ctypeslib.as_array(ptr, shape=(n,)).copy().reshape(shape) if n else np.zeros(shape, ctype)
+    C.CDLL(None).free(C.cast(ptr, vp))
+    return a
+
+
+def findLsTriplets(ls_dirs_deg, omitLarge=0):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    v, f = fp(), ip()
+    nv, nf = C.c_int(), C.c_int()
+    load().findLsTriplets(_f(d), d.shape[0], omitLarge, C.byref(v), C.byref(nv), C.byref(f), C.byref(nf))
+    V = _take(v, (nv.value, 3))
+    Fc = _take(f, (nf.value, 3), np.int32) if nf.value else np.zeros((0, 3), np.int32)
+    return V, Fc
+
+
+def generateVBAPgainTable3D_srcs(src_dirs_deg, ls_dirs_deg, omitLarge=0, dummies=0, spread=0.0):
+    s = np.ascontiguousarray(src_dirs_deg, np.float32).reshape(-1, 2)
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    g = fp()
+    n, nt = C.c_int(), C.c_int()
+    load().generateVBAPgainTable3D_srcs(_f(s), s.shape[0], _f(d), d.shape[0], omitLarge, dummies, C.c_float(spread), C.byref(g), C.byref(n), C.byref(nt))
+    return _take(g, (n.value, d.shape[0])), nt.value
+
+
+def generateVBAPgainTable3D(ls_dirs_deg, az_res, el_res, omitLarge=0, dummies=0, spread=0.0):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    g = fp()
+    n, nt = C.c_int(), C.c_int()
+    load().generateVBAPgainTable3D(_f(d), d.shape[0], az_res, el_res, omitLarge, dummies, C.c_float(spread), C.byref(g), C.byref(n), C.byref(nt))
+    return _take(g, (n.value, d.shape[0])), nt.value
+
+
+def compressVBAPgainTable3D(gt):
+    gt = np.ascontiguousarray(gt, np.float32)
+    comp = np.zeros((gt.shape[0], 3), np.float32)
+    idx = np.zeros((gt.shape[0], 3), np.int32)
+    load().compressVBAPgainTable3D(_f(gt), gt.shape[0], gt.shape[1], _f(comp), idx.ctypes.data_as(ip))
+    return comp, idx
+
+
+# ---------------------------------------------------------------- ambi_dec
+class AmbiDec:
+    """examples/include/ambi_dec.h.  `frameSize` plays the role of -DAMBI_DEC_FRAME_SIZE."""
+
+    def __init__(self, frameSize=128):
+        self.L = load()
+        self.L.saf_hip_ambi_dec_setFrameSize(frameSize)
+        self.h = vp()
+        self.F = frameSize
+        self.L.ambi_dec_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "ambi_dec_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def setLoudspeakersDeg(self, dirs):
+        d = np.asarray(dirs, np.float32).reshape(-1, 2)
+        self.L.ambi_dec_setNumLoudspeakers(self.h, d.shape[0])
+        for i in range(d.shape[0]):
+            self.L.ambi_dec_setLoudspeakerAzi_deg(self.h, i, C.c_float(float(d[i, 0])))
+            self.L.ambi_dec_setLoudspeakerElev_deg(self.h, i, C.c_float(float(d[i, 1])))
+
+    def process(self, x, nOut, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.ambi_dec_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def decMtx(self, dec, order, maxrE, nLS):
+        M = np.zeros((nLS, (order + 1) ** 2), np.float32)
+        self.L.saf_hip_ambi_dec_getDecoderMtx(self.h, dec, order, maxrE, _f(M))
+        return M
+
+    def Mnorm(self, dec, order, which):
+        return self.L.saf_hip_ambi_dec_getDecoderNorm(self.h, dec, order, which)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ambi_dec_destroy(C.byref(self.h))
+
+
+class AmbiDecBatch:
+    """saf_hip_ambi_dec_batch_*: nInst initialised handles, device-resident blocks."""
+
+    def __init__(self, decoders, maxFramesPerCall):
+        self.L = load()
+        self.decoders = list(decoders)          # keep the handles alive
+        arr = (vp * len(self.decoders))(*[d.h for d in self.decoders])
+        self.nInst = len(self.decoders)
+        self.hb = vp(self.L.saf_hip_ambi_dec_batch_create(arr, self.nInst, maxFramesPerCall))
+
+    def process_ptr(self, d_in, in_strides, d_out, out_strides, nFrames):
+        """strides = (inst, frame, ch) in floats."""
+        self.L.saf_hip_ambi_dec_batch_process(self.hb, vp(d_in), *in_strides, vp(d_out), *out_strides, nFrames)
+
+    def clear(self):
+        self.L.saf_hip_ambi_dec_batch_clear(self.hb)
+
+    def __del__(self):
+        if getattr(self, "hb", None):
+            self.L.saf_hip_ambi_dec_batch_destroy(C.byref(self.hb))

@@ -1,0 +1,531 @@
+/*
+ * ambi_dec.cpp — the ambi_dec operator (examples/include/ambi_dec.h:114-520,
+ * examples/src/ambi_dec/ambi_dec.c, ambi_dec_internal.c) with its per-block path
+ * on the GPU:
+ *
+ *   inputs -> [afSTFT analysis kernel: SN3D/FuMa conversion folded in]
+ *          -> [band-batched MFMA GEMM with the (decoder, order, maxrE, norm) matrix of each band]
+ *          -> [afSTFT synthesis kernel] -> outputs
+ *
+ * The codec state machine, parameter snapshotting and "zero the output when not
+ * ready" behaviour follow the reference.  The device pipeline is shared by the
+ * single-handle ambi_dec_process (host pointers, one block) and the batched
+ * device-pointer entry point (many instances x many blocks per launch).
+ */
+#include "saf_hip_common.h"
+#include "../../include/saf_hip.h"
+#include "afstft_state.h"
+#include "design_host.h"
+#include "presets.h"
+#include <thread>
+#include <chrono>
+
+namespace saf {
+
+#define NUM_DECODERS 2
+#define NMAT (NUM_DECODERS * SAF_MAX_ORDER)
+static int g_ambi_dec_frame_size = 128;    /* default of the reference (ambi_dec_internal.h:65) */
+
+static inline void sleep_ms(int ms) { std::this_thread::sleep_for(std::chrono::milliseconds(ms)); }
+
+struct AmbiDec {
+    int F, T;
+    /* designed codec tables (ambi_dec_codecPars, ambi_dec_internal.h:86-121) */
+    std::vector<float> M_dec[NUM_DECODERS][SAF_MAX_ORDER], M_dec_maxrE[NUM_DECODERS][SAF_MAX_ORDER];
+    float M_norm[NUM_DECODERS][SAF_MAX_ORDER][2];
+    std::string sofa_filepath;
+    int hrir_fs = 0;
+    /* (ambi_dec_data, ambi_dec_internal.h:127-173) */
+    float freqVector[SAF_NBANDS];
+    int fs = 48000;
+    volatile CODEC_STATUS codecStatus;
+    volatile PROC_STATUS procStatus;
+    float progressBar0_1;
+    char progressBarText[PROGRESSBARTEXT_CHAR_LENGTH];
+    int loudpkrs_nDims, new_nLoudpkrs, new_binauraliseLS, new_masterOrder;
+    int reinit_hrtfsFLAG, recalc_hrtf_interpFLAG[SAF_MAXCH];
+    int masterOrder, orderPerBand[SAF_NBANDS];
+    int dec_method[NUM_DECODERS], rE_WEIGHT[NUM_DECODERS], diffEQmode[NUM_DECODERS];
+    float transitionFreq;
+    int nLoudpkrs;
+    float loudpkrs_dirs_deg[SAF_MAXCH][2];
+    int useDefaultHRIRsFLAG, enableHRIRsPreProc, binauraliseLS;
+    CH_ORDER chOrdering;
+    NORM_TYPES norm;
+    /* device side */
+    bool haveSTFT = false;
+    unsigned long long codecEpoch = 0;     /* bumped by every initCodec; pipelines re-read the tables when it changes */
+    struct DecPipeline* pipe = nullptr;    /* single-instance pipeline of ambi_dec_process */
+    PinBuf<float> h_in, h_out;
+    DevBuf<float> d_in, d_out;
+};
+
+/* -------------------------------------------------------------------------- */
+/*  device pipeline for nInst instances                                       */
+/* -------------------------------------------------------------------------- */
+struct DecPipeline {
+    int nInst = 0, F = 0, T = 0, maxFrames = 0, Hmax = 0, nSH = 0, nLS = 0;
+    std::vector<AmbiDec*> inst;
+    AfState st;
+    DevBuf<float2> X, Y;            /* [nInst][133][64][Hmax] */
+    DevBuf<float> Afrag;            /* [nInst][NMAT][2][32][64] */
+    DevBuf<int> band2mat;           /* [nInst][133] */
+    DevBuf<float> chScale;          /* [nInst][64] */
+    DevBuf<int> chMap;              /* [nInst][64] */
+    /* host shadows to detect parameter changes between calls */
+    struct Shadow {
+        unsigned long long epoch = ~0ull;
+        int rE[2] = { -1, -1 }, eq[2] = { -1, -1 };
+        int b2m[SAF_NBANDS];
+        int norm = -1, chOrd = -1;
+        bool b2mValid = false;
+    };
+    std::vector<Shadow> shadow;
+    PinBuf<float> stageA; PinBuf<int> stageI; PinBuf<float> stageS;
+
+    void create(AmbiDec* const* handles, int n, int maxFrames_)
+    {
+        nInst = n; inst.assign(handles, handles + n);
+        F = inst[0]->F; T = F / SAF_HOP; maxFrames = maxFrames_; Hmax = T * maxFrames;
+        nSH = ORDER2NSH(inst[0]->masterOrder); nLS = inst[0]->nLoudpkrs;
+        for (int i = 0; i < n; i++) {
+            if (inst[i]->F != F) SAF_FATAL("ambi_dec batch: all instances must use the same block size");
+            if (inst[i]->codecStatus != CODEC_STATUS_INITIALISED) SAF_FATAL("ambi_dec batch: instance %d is not initialised (call ambi_dec_initCodec)", i);
+            if (ORDER2NSH(inst[i]->masterOrder) != nSH || inst[i]->nLoudpkrs != nLS)
+                SAF_FATAL("ambi_dec batch: all instances must share master order and loudspeaker count");
+            if (inst[i]->binauraliseLS) SAF_FATAL("ambi_dec batch: binauralised output is not implemented in this build");
+        }
+        st.create(nInst, nSH, nLS);
+        X.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, false);
+        Y.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, false);
+        Afrag.alloc((size_t)nInst * NMAT * 64 * 64);
+        band2mat.alloc((size_t)nInst * SAF_NBANDS);
+        chScale.alloc((size_t)nInst * SAF_MAXCH);
+        chMap.alloc((size_t)nInst * SAF_MAXCH);
+        shadow.assign(nInst, Shadow());
+        stageA.ensure((size_t)NMAT * 64 * 64); stageI.ensure(SAF_NBANDS + SAF_MAXCH); stageS.ensure(SAF_MAXCH);
+    }
+
+    /* push per-instance tables whose inputs changed since the previous call (parameters are
+     * snapshotted at the start of a block like ambi_dec.c:479-488) */
+    void refresh()
+    {
+        for (int i = 0; i < nInst; i++) {
+            AmbiDec* p = inst[i];
+            Shadow& s = shadow[i];
+            const int rE[2] = { p->rE_WEIGHT[0], p->rE_WEIGHT[1] }, eq[2] = { p->diffEQmode[0], p->diffEQmode[1] };
+            if (s.epoch != p->codecEpoch || s.rE[0] != rE[0] || s.rE[1] != rE[1] || s.eq[0] != eq[0] || s.eq[1] != eq[1]) {
+                /* effective matrix of (decoder d, order n): M_norm * (maxrE ? M_dec_maxrE : M_dec), zero-padded 64x64
+                 * (ambi_dec.c:524-539) */
+                HIP_CHECK(hipStreamSynchronize(stream()));       /* staging buffer may still be in flight */
+                std::vector<float> A(64 * 64);
+                for (int d = 0; d < NUM_DECODERS; d++)
+                    for (int n = 1; n <= SAF_MAX_ORDER; n++) {
+                        std::fill(A.begin(), A.end(), 0.0f);
+                        if (n <= p->masterOrder) {
+                            const int nSHo = ORDER2NSH(n);
+                            const std::vector<float>& M = rE[d] ? p->M_dec_maxrE[d][n - 1] : p->M_dec[d][n - 1];
+                            const float sc = p->M_norm[d][n - 1][eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
+                            for (int l = 0; l < p->nLoudpkrs; l++)
+                                for (int k = 0; k < nSHo; k++) A[l * 64 + k] = M[(size_t)l * nSHo + k] * sc;
+                        }
+                        pack_A(A.data(), stageA.p + (size_t)(d * SAF_MAX_ORDER + n - 1) * 64 * 64);
+                    }
+                HIP_CHECK(hipMemcpyAsync(Afrag.p + (size_t)i * NMAT * 64 * 64, stageA.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream()));
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                s.epoch = p->codecEpoch; s.rE[0] = rE[0]; s.rE[1] = rE[1]; s.eq[0] = eq[0]; s.eq[1] = eq[1];
+                s.b2mValid = false; s.norm = -1;
+            }
+            int b2m[SAF_NBANDS];
+            for (int band = 0; band < SAF_NBANDS; band++) {
+                int ob = p->orderPerBand[band] < p->masterOrder ? p->orderPerBand[band] : p->masterOrder;
+                if (ob < 1) ob = 1;
+                const int decIdx = p->freqVector[band] < p->transitionFreq ? 0 : 1;      /* ambi_dec.c:519-523 */
+                b2m[band] = decIdx * SAF_MAX_ORDER + ob - 1;
+            }
+            if (!s.b2mValid || memcmp(b2m, s.b2m, sizeof(b2m)) != 0) {
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                memcpy(stageI.p, b2m, sizeof(b2m));
+                HIP_CHECK(hipMemcpyAsync(band2mat.p + (size_t)i * SAF_NBANDS, stageI.p, sizeof(b2m), hipMemcpyHostToDevice, stream()));
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                memcpy(s.b2m, b2m, sizeof(b2m)); s.b2mValid = true;
+            }
+            if (s.norm != (int)p->norm || s.chOrd != (int)p->chOrdering) {
+                /* input conventions -> ACN/N3D (ambi_dec.c:500-511, saf_hoa.c:40-116) as a gather map + row scale */
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                int* map = stageI.p; float* sc = stageS.p;
+                for (int ch = 0; ch < SAF_MAXCH; ch++) { map[ch] = ch; sc[ch] = 1.0f; }
+                if (p->chOrdering == CH_FUMA) {
+                    /* FuMa WXYZ -> ACN WYZX, first order only; higher channels are zeroed (saf_hoa.c:58-69) */
+                    map[1] = 2; map[2] = 3; map[3] = 1;
+                    for (int ch = 4; ch < SAF_MAXCH; ch++) map[ch] = -1;
+                }
+                if (p->norm == NORM_SN3D) {
+                    for (int n = 0; n <= p->masterOrder; n++)
+                        for (int ch = n * n; ch < ORDER2NSH(n); ch++) sc[ch] = sqrtf(2.0f * (float)n + 1.0f);
+                } else if (p->norm == NORM_FUMA) {
+                    sc[0] = sqrtf(2.0f);
+                    for (int ch = 1; ch < 4; ch++) sc[ch] = sqrtf(3.0f);
+                }
+                HIP_CHECK(hipMemcpyAsync(chMap.p + (size_t)i * SAF_MAXCH, map, sizeof(int) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
+                HIP_CHECK(hipMemcpyAsync(chScale.p + (size_t)i * SAF_MAXCH, sc, sizeof(float) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                s.norm = (int)p->norm; s.chOrd = (int)p->chOrdering;
+            }
+        }
+    }
+
+    void process(const float* d_in, long long in_inst, long long in_frame, long long in_ch, int nChPresent,
+                 float* d_out, long long out_inst, long long out_frame, long long out_ch, int nFrames)
+    {
+        if (nFrames <= 0) return;
+        if (nFrames > maxFrames) SAF_FATAL("ambi_dec batch: nFrames %d exceeds the maxFramesPerCall %d given at creation", nFrames, maxFrames);
+        refresh();
+        const int H = nFrames * T;
+        AnaLaunch a{};
+        a.in = d_in; a.in_inst = in_inst; a.in_ch = in_ch; a.in_frame = in_frame; a.hopsPerFrame = T; a.nChIn = nChPresent;
+        a.hist_rd = st.ana[st.anaPar].p; a.hist_wr = st.ana[st.anaPar ^ 1].p;
+        a.out = X.p; a.out_inst = (long long)SAF_NBANDS * SAF_MAXCH * Hmax; a.out_band = (long long)SAF_MAXCH * Hmax; a.out_ch = Hmax;
+        a.ch_scale = chScale.p; a.ch_map = chMap.p;
+        a.nCh = nSH; a.nInst = nInst; a.H = H; a.lowDelay = 0; a.hybrid = 1;
+        a.tab_stride = SAF_MAXCH;
+        launch_analysis(a);
+        st.anaPar ^= 1;
+
+        BandGemmLaunch g{};
+        g.X = (const float*)X.p; g.x_inst = 2 * a.out_inst; g.x_band = 2 * a.out_band; g.x_row = 2 * a.out_ch;
+        g.Y = (float*)Y.p; g.y_inst = g.x_inst; g.y_band = g.x_band; g.y_row = g.x_row;
+        g.Afrag = Afrag.p; g.a_inst = (long long)NMAT * 64 * 64; g.band2mat = band2mat.p;
+        g.nBands = SAF_NBANDS; g.nInst = nInst; g.N = 2 * H;
+        launch_band_gemm(g);
+
+        SynLaunch s{};
+        s.in = Y.p; s.in_inst = a.out_inst; s.in_band = a.out_band; s.in_ch = a.out_ch;
+        s.out = d_out; s.out_inst = out_inst; s.out_ch = out_ch; s.out_frame = out_frame; s.hopsPerFrame = T;
+        s.hist_rd = st.syn[st.synPar].p; s.hist_wr = st.syn[st.synPar ^ 1].p;
+        s.nCh = nLS; s.nInst = nInst; s.H = H; s.lowDelay = 0; s.hybrid = 1;
+        launch_synthesis(s);
+        st.synPar ^= 1;
+    }
+};
+
+/* -------------------------------------------------------------------------- */
+
+static void set_codec_status(AmbiDec* p, CODEC_STATUS s)     /* ambi_dec_internal.c:48-57 */
+{
+    if (s == CODEC_STATUS_NOT_INITIALISED)
+        while (p->codecStatus == CODEC_STATUS_INITIALISING) sleep_ms(10);
+    p->codecStatus = s;
+}
+
+}  // namespace saf
+
+using namespace saf;
+
+extern "C" {
+
+void saf_hip_ambi_dec_setFrameSize(int frameSize)
+{
+    if (frameSize <= 0 || frameSize % SAF_HOP != 0) SAF_FATAL("ambi_dec frame size must be a positive multiple of 128");
+    g_ambi_dec_frame_size = frameSize;
+}
+
+void ambi_dec_create(void** const phAmbi)
+{
+    AmbiDec* p = new AmbiDec();
+    *phAmbi = p;
+    p->F = g_ambi_dec_frame_size; p->T = p->F / SAF_HOP;
+    load_loudspeaker_preset(LOUDSPEAKER_ARRAY_PRESET_T_DESIGN_24, p->loudpkrs_dirs_deg, &p->new_nLoudpkrs, &p->loudpkrs_nDims);
+    p->masterOrder = p->new_masterOrder = 1;
+    for (int b = 0; b < SAF_NBANDS; b++) p->orderPerBand[b] = 1;
+    p->useDefaultHRIRsFLAG = 1; p->enableHRIRsPreProc = 1;
+    p->nLoudpkrs = p->new_nLoudpkrs;
+    p->chOrdering = CH_ACN; p->norm = NORM_SN3D;
+    p->dec_method[0] = p->dec_method[1] = DECODING_METHOD_ALLRAD;
+    p->rE_WEIGHT[0] = p->rE_WEIGHT[1] = 1;
+    p->diffEQmode[0] = p->diffEQmode[1] = ENERGY_PRESERVING;
+    p->transitionFreq = 800.0f;
+    p->progressBar0_1 = 0.0f; p->progressBarText[0] = 0;
+    p->codecStatus = CODEC_STATUS_NOT_INITIALISED;
+    p->binauraliseLS = p->new_binauraliseLS = 0;
+    p->procStatus = PROC_STATUS_NOT_ONGOING;
+    p->reinit_hrtfsFLAG = 1;
+    for (int ch = 0; ch < SAF_MAXCH; ch++) p->recalc_hrtf_interpFLAG[ch] = 1;
+    memset(p->freqVector, 0, sizeof(p->freqVector));
+    memset(p->M_norm, 0, sizeof(p->M_norm));
+}
+
+void ambi_dec_destroy(void** const phAmbi)
+{
+    AmbiDec* p = (AmbiDec*)*phAmbi;
+    if (!p) return;
+    while (p->codecStatus == CODEC_STATUS_INITIALISING || p->procStatus == PROC_STATUS_ONGOING) sleep_ms(10);
+    if (p->pipe) { HIP_CHECK(hipStreamSynchronize(stream())); delete p->pipe; }
+    delete p;
+    *phAmbi = nullptr;
+}
+
+void ambi_dec_init(void* const hAmbi, int sampleRate)
+{
+    AmbiDec* p = (AmbiDec*)hAmbi;
+    p->fs = sampleRate;
+    /* before the first initCodec there is no filterbank yet: the NULL-handle table branch (ambi_dec.c:178, afSTFTlib.c:554-563) */
+    if (!p->haveSTFT) afSTFT_getCentreFreqs(nullptr, (float)sampleRate, SAF_NBANDS, p->freqVector);
+    else {   /* valid-handle branch of afSTFT_getCentreFreqs (afSTFTlib.c:565-587), hop 128 hybrid */
+        static const float w[9] = { 1.0f, 0.7501f, 1.2499f, 0.8751f, 1.1249f, 0.9167f, 1.0833f, 0.9375f, 1.0625f };
+        static const int bin[9] = { 0, 1, 1, 2, 2, 3, 3, 4, 4 };
+        for (int i = 0; i < 9; i++) p->freqVector[i] = w[i] * ((float)bin[i] * (float)sampleRate / 256.0f);
+        for (int i = 9, j = 5; i < SAF_NBANDS; i++, j++) p->freqVector[i] = (float)j * (float)sampleRate / 256.0f;
+    }
+}
+
+void ambi_dec_initCodec(void* const hAmbi)
+{
+    AmbiDec* p = (AmbiDec*)hAmbi;
+    if (p->codecStatus != CODEC_STATUS_NOT_INITIALISED) return;          /* ambi_dec.c:196-197 */
+    while (p->procStatus == PROC_STATUS_ONGOING) { p->codecStatus = CODEC_STATUS_INITIALISING; sleep_ms(10); }
+    ensure_device();
+    p->codecStatus = CODEC_STATUS_INITIALISING;
+    strcpy(p->progressBarText, "Initialising");
+    p->progressBar0_1 = 0.0f;
+
+    const int masterOrder = p->new_masterOrder;
+    const int max_nSH = ORDER2NSH(masterOrder);
+    int nLS = p->new_nLoudpkrs;
+    /* (re)create the filterbank state: channel change + clearBuffers == fresh zero state (ambi_dec.c:213-226) */
+    if (p->pipe) { HIP_CHECK(hipStreamSynchronize(stream())); delete p->pipe; p->pipe = nullptr; }
+    p->haveSTFT = true;
+    p->binauraliseLS = p->new_binauraliseLS;
+    p->nLoudpkrs = nLS;
+
+    strcpy(p->progressBarText, "Computing decoder");
+    p->progressBar0_1 = 0.2f;
+    float sum_elev = 0.0f;
+    for (int ch = 0; ch < nLS; ch++) sum_elev += fabsf(p->loudpkrs_dirs_deg[ch][1]);
+    p->loudpkrs_nDims = (((sum_elev < 5.0f) && (sum_elev > -5.0f)) || (nLS < 4)) ? 2 : 3;
+    const bool virt = p->loudpkrs_nDims == 2 && (p->dec_method[0] == DECODING_METHOD_ALLRAD || p->dec_method[1] == DECODING_METHOD_ALLRAD);
+    if (virt) {      /* virtual loudspeakers above/below so a 2-D layout triangulates (ambi_dec.c:241-249) */
+        if (nLS > SAF_MAXCH - 2) SAF_FATAL("ambi_dec: a 2-D layout needs two spare loudspeaker slots for AllRAD");
+        p->loudpkrs_dirs_deg[nLS][0] = 0.0f; p->loudpkrs_dirs_deg[nLS][1] = -90.0f;
+        p->loudpkrs_dirs_deg[nLS + 1][0] = 0.0f; p->loudpkrs_dirs_deg[nLS + 1][1] = 90.0f;
+        nLS += 2;
+    }
+
+    /* SH of the 480-point t-design, evaluated once per order on the GPU (ambi_dec.c:304-320 evaluates getSHreal per direction) */
+    const int nGrid = 480;
+    const float* grid = table_required("Tdesign_degree_30_dirs_deg", nGrid * 2);
+    std::vector<float> grid_rad((size_t)nGrid * 2);
+    for (int ng = 0; ng < nGrid; ng++) {
+        grid_rad[ng * 2] = grid[ng * 2] * SAF_PI / 180.0f;
+        grid_rad[ng * 2 + 1] = SAF_PI / 2.0f - grid[ng * 2 + 1] * SAF_PI / 180.0f;
+    }
+    std::vector<float> Ygrid((size_t)max_nSH * nGrid);
+    sh_eval_host(0, masterOrder, grid_rad.data(), nGrid, Ygrid.data());
+
+    static const int method_map[5] = { LOUDSPEAKER_DECODER_SAD, LOUDSPEAKER_DECODER_SAD, LOUDSPEAKER_DECODER_MMD, LOUDSPEAKER_DECODER_EPAD, LOUDSPEAKER_DECODER_ALLRAD };
+    std::vector<float> M_tmp((size_t)nLS * max_nSH), g(nLS);
+    for (int d = 0; d < NUM_DECODERS; d++) {
+        const int dm = p->dec_method[d];
+        decoder_matrix(&p->loudpkrs_dirs_deg[0][0], nLS, (dm >= 1 && dm <= 4) ? method_map[dm] : LOUDSPEAKER_DECODER_SAD, masterOrder, 0, M_tmp.data());
+        for (int n = 1; n <= masterOrder; n++) {
+            const int nSHo = ORDER2NSH(n);
+            std::vector<float>& M = p->M_dec[d][n - 1];
+            std::vector<float>& Mr = p->M_dec_maxrE[d][n - 1];
+            M.assign((size_t)nLS * nSHo, 0.0f); Mr.assign((size_t)nLS * nSHo, 0.0f);
+            for (int i = 0; i < nLS; i++) for (int j = 0; j < nSHo; j++) M[(size_t)i * nSHo + j] = M_tmp[(size_t)i * max_nSH + j];
+            std::vector<float> a_n; maxre_weights(n, a_n);
+            for (int i = 0; i < nLS; i++) for (int j = 0; j < nSHo; j++) Mr[(size_t)i * nSHo + j] = M[(size_t)i * nSHo + j] * a_n[j];
+            /* omni amplitude / energy of the non-maxrE decoder over the t-design (ambi_dec.c:304-331).
+             * The SH of order n are the first (n+1)^2 rows of the order-N evaluation. */
+            float a_avg = 0.0f, e_avg = 0.0f;
+            for (int ng = 0; ng < nGrid; ng++) {
+                float a = 0.0f, e = 0.0f;
+                for (int i = 0; i < nLS; i++) {
+                    float acc = 0.0f;
+                    for (int j = 0; j < nSHo; j++) acc += M[(size_t)i * nSHo + j] * Ygrid[(size_t)j * nGrid + ng];
+                    g[i] = acc;
+                }
+                for (int i = 0; i < nLS; i++) { a += g[i]; e += powf(g[i], 2.0f); }
+                a_avg += a; e_avg += e;
+            }
+            a_avg /= (float)nGrid; e_avg /= (float)nGrid;
+            p->M_norm[d][n - 1][0] = 1.0f / (a_avg + 2.23e-6f);
+            p->M_norm[d][n - 1][1] = sqrtf(1.0f / (e_avg + 2.23e-6f));
+            if (virt) { M.resize((size_t)p->nLoudpkrs * nSHo); Mr.resize((size_t)p->nLoudpkrs * nSHo); }   /* ambi_dec.c:336-341 */
+        }
+    }
+    p->masterOrder = p->new_masterOrder;
+
+    /* HRIR branch (ambi_dec.c:350-445): needs the default HRIR set, which neither the reference
+     * checkout (.MISSING_LARGE_BLOBS) nor this build ships; binauralised output is "next" (SURVEY §8f-2). */
+    p->reinit_hrtfsFLAG = 0;
+
+    p->codecEpoch++;
+    strcpy(p->progressBarText, "Done!");
+    p->progressBar0_1 = 1.0f;
+    p->codecStatus = CODEC_STATUS_INITIALISED;
+}
+
+void ambi_dec_process(void* const hAmbi, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples)
+{
+    AmbiDec* p = (AmbiDec*)hAmbi;
+    const int F = p->F;
+    if (nSamples == F && p->codecStatus == CODEC_STATUS_INITIALISED && !p->binauraliseLS) {
+        p->procStatus = PROC_STATUS_ONGOING;
+        const int nSH = ORDER2NSH(p->masterOrder), nLS = p->nLoudpkrs;
+        if (!p->pipe) {
+            p->pipe = new DecPipeline();
+            AmbiDec* self = p;
+            p->pipe->create(&self, 1, 1);
+            p->h_in.ensure((size_t)SAF_MAXCH * F); p->h_out.ensure((size_t)SAF_MAXCH * F);
+            p->d_in.alloc((size_t)SAF_MAXCH * F, false); p->d_out.alloc((size_t)SAF_MAXCH * F, false);
+        }
+        int i;
+        const int nPresent = nSH < nInputs ? nSH : nInputs;
+        for (i = 0; i < nPresent; i++) memcpy(p->h_in.p + (size_t)i * F, inputs[i], sizeof(float) * F);
+        /* a FuMa gather may read rows up to 3: make them defined */
+        for (; i < (nSH < 4 ? 4 : nSH) && i < SAF_MAXCH; i++) memset(p->h_in.p + (size_t)i * F, 0, sizeof(float) * F);
+        const int nRows = (nSH < 4 ? 4 : nSH);
+        HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nRows * F, hipMemcpyHostToDevice, stream()));
+        p->pipe->process(p->d_in.p, 0, 0, F, nRows, p->d_out.p, 0, 0, F, 1);
+        HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nLS * F, hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        int ch;
+        for (ch = 0; ch < (nLS < nOutputs ? nLS : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);
+        for (; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);
+    } else
+        for (int ch = 0; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);      /* ambi_dec.c:575-577 */
+    p->procStatus = PROC_STATUS_NOT_ONGOING;
+}
+
+/* ------------------------------- set functions (ambi_dec.c:585-810) ------------------------------- */
+#define PD AmbiDec* p = (AmbiDec*)hAmbi
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void ambi_dec_refreshSettings(void* const hAmbi)
+{
+    PD;
+    for (int ch = 0; ch < SAF_MAXCH; ch++) p->recalc_hrtf_interpFLAG[ch] = 1;
+    p->reinit_hrtfsFLAG = 1;
+    set_codec_status(p, CODEC_STATUS_NOT_INITIALISED);
+}
+void ambi_dec_setMasterDecOrder(void* const hAmbi, int newValue)
+{
+    PD;
+    p->new_masterOrder = clampi(newValue, 1, SAF_MAX_ORDER);
+    set_codec_status(p, CODEC_STATUS_NOT_INITIALISED);
+    if (p->new_masterOrder != 1 && p->chOrdering == CH_FUMA) p->chOrdering = CH_ACN;     /* FuMa is first-order only */
+    if (p->new_masterOrder != 1 && p->norm == NORM_FUMA) p->norm = NORM_SN3D;
+}
+void ambi_dec_setDecOrder(void* const hAmbi, int newValue, int bandIdx) { PD; p->orderPerBand[bandIdx] = clampi(newValue, 1, p->new_masterOrder); }
+void ambi_dec_setDecOrderAllBands(void* const hAmbi, int newValue) { PD; for (int b = 0; b < SAF_NBANDS; b++) p->orderPerBand[b] = clampi(newValue, 1, p->new_masterOrder); }
+void ambi_dec_setLoudspeakerAzi_deg(void* const hAmbi, int index, float v)
+{
+    PD;
+    if (v > 180.0f) v = -360.0f + v;
+    v = v < -180.0f ? -180.0f : (v > 180.0f ? 180.0f : v);
+    if (p->loudpkrs_dirs_deg[index][0] != v) { p->loudpkrs_dirs_deg[index][0] = v; p->recalc_hrtf_interpFLAG[index] = 1; set_codec_status(p, CODEC_STATUS_NOT_INITIALISED); }
+}
+void ambi_dec_setLoudspeakerElev_deg(void* const hAmbi, int index, float v)
+{
+    PD;
+    v = v < -90.0f ? -90.0f : (v > 90.0f ? 90.0f : v);
+    if (p->loudpkrs_dirs_deg[index][1] != v) { p->loudpkrs_dirs_deg[index][1] = v; p->recalc_hrtf_interpFLAG[index] = 1; set_codec_status(p, CODEC_STATUS_NOT_INITIALISED); }
+}
+void ambi_dec_setNumLoudspeakers(void* const hAmbi, int n)
+{
+    PD;
+    p->new_nLoudpkrs = clampi(n, 4 /* MIN_NUM_LOUDSPEAKERS */, SAF_MAXCH);
+    if (p->nLoudpkrs != p->new_nLoudpkrs) {
+        for (int ch = 0; ch < SAF_MAXCH; ch++) p->recalc_hrtf_interpFLAG[ch] = 1;
+        set_codec_status(p, CODEC_STATUS_NOT_INITIALISED);
+    }
+}
+void ambi_dec_setBinauraliseLSflag(void* const hAmbi, int newState) { PD; p->new_binauraliseLS = newState; if (p->new_binauraliseLS != p->binauraliseLS) set_codec_status(p, CODEC_STATUS_NOT_INITIALISED); }
+void ambi_dec_setUseDefaultHRIRsflag(void* const hAmbi, int newState) { PD; if (!p->useDefaultHRIRsFLAG && newState) { p->useDefaultHRIRsFLAG = newState; ambi_dec_refreshSettings(hAmbi); } }
+void ambi_dec_setSofaFilePath(void* const hAmbi, const char* path) { PD; p->sofa_filepath = path; p->useDefaultHRIRsFLAG = 0; ambi_dec_refreshSettings(hAmbi); }
+void ambi_dec_setEnableHRIRsPreProc(void* const hAmbi, int newState) { PD; if (newState != p->enableHRIRsPreProc) { p->enableHRIRsPreProc = newState; ambi_dec_refreshSettings(hAmbi); } }
+void ambi_dec_setOutputConfigPreset(void* const hAmbi, int newPresetID)
+{
+    PD;
+    load_loudspeaker_preset(newPresetID, p->loudpkrs_dirs_deg, &p->new_nLoudpkrs, &p->loudpkrs_nDims);
+    for (int ch = 0; ch < SAF_MAXCH; ch++) p->recalc_hrtf_interpFLAG[ch] = 1;
+    set_codec_status(p, CODEC_STATUS_NOT_INITIALISED);
+}
+void ambi_dec_setSourcePreset(void* const hAmbi, int newPresetID)
+{
+    PD;
+    mic_preset_order_per_band(newPresetID, p->masterOrder, p->freqVector, SAF_NBANDS, p->orderPerBand);
+}
+void ambi_dec_setChOrder(void* const hAmbi, int v) { PD; if ((CH_ORDER)v != CH_FUMA || p->new_masterOrder == 1) p->chOrdering = (CH_ORDER)v; }
+void ambi_dec_setNormType(void* const hAmbi, int v) { PD; if ((NORM_TYPES)v != NORM_FUMA || p->new_masterOrder == 1) p->norm = (NORM_TYPES)v; }
+void ambi_dec_setDecMethod(void* const hAmbi, int index, int newID) { PD; p->dec_method[index] = newID; set_codec_status(p, CODEC_STATUS_NOT_INITIALISED); }
+void ambi_dec_setDecEnableMaxrE(void* const hAmbi, int index, int newID) { PD; p->rE_WEIGHT[index] = newID; }
+void ambi_dec_setDecNormType(void* const hAmbi, int index, int newID) { PD; p->diffEQmode[index] = newID; }
+void ambi_dec_setTransitionFreq(void* const hAmbi, float v) { PD; p->transitionFreq = v < 500.0f ? 500.0f : (v > 2000.0f ? 2000.0f : v); }   /* ambi_dec.h:99-102 */
+
+/* ------------------------------- get functions (ambi_dec.c:813-988) ------------------------------- */
+int ambi_dec_getFrameSize(void) { return g_ambi_dec_frame_size; }
+CODEC_STATUS ambi_dec_getCodecStatus(void* const hAmbi) { PD; return p->codecStatus; }
+float ambi_dec_getProgressBar0_1(void* const hAmbi) { PD; return p->progressBar0_1; }
+void ambi_dec_getProgressBarText(void* const hAmbi, char* text) { PD; memcpy(text, p->progressBarText, PROGRESSBARTEXT_CHAR_LENGTH); }
+int ambi_dec_getMasterDecOrder(void* const hAmbi) { PD; return p->new_masterOrder; }
+int ambi_dec_getDecOrder(void* const hAmbi, int bandIdx) { PD; return p->orderPerBand[bandIdx]; }
+int ambi_dec_getDecOrderAllBands(void* const hAmbi) { PD; return p->orderPerBand[0]; }
+void ambi_dec_getDecOrderHandle(void* const hAmbi, float** pX_vector, int** pY_values, int* pNpoints) { PD; *pX_vector = &p->freqVector[0]; *pY_values = &p->orderPerBand[0]; *pNpoints = SAF_NBANDS; }
+int ambi_dec_getNumberOfBands(void) { return SAF_NBANDS; }
+float ambi_dec_getLoudspeakerAzi_deg(void* const hAmbi, int index) { PD; return p->loudpkrs_dirs_deg[index][0]; }
+float ambi_dec_getLoudspeakerElev_deg(void* const hAmbi, int index) { PD; return p->loudpkrs_dirs_deg[index][1]; }
+int ambi_dec_getNumLoudspeakers(void* const hAmbi) { PD; return p->new_nLoudpkrs; }
+int ambi_dec_getMaxNumLoudspeakers(void) { return SAF_MAXCH; }
+int ambi_dec_getNSHrequired(void* const hAmbi) { PD; return ORDER2NSH(p->masterOrder); }
+int ambi_dec_getBinauraliseLSflag(void* const hAmbi) { PD; return p->new_binauraliseLS; }
+int ambi_dec_getUseDefaultHRIRsflag(void* const hAmbi) { PD; return p->useDefaultHRIRsFLAG; }
+char* ambi_dec_getSofaFilePath(void* const hAmbi) { PD; return p->sofa_filepath.empty() ? (char*)"no_file" : (char*)p->sofa_filepath.c_str(); }
+int ambi_dec_getEnableHRIRsPreProc(void* const hAmbi) { PD; return p->enableHRIRsPreProc; }
+int ambi_dec_getChOrder(void* const hAmbi) { PD; return (int)p->chOrdering; }
+int ambi_dec_getNormType(void* const hAmbi) { PD; return (int)p->norm; }
+int ambi_dec_getDecMethod(void* const hAmbi, int index) { PD; return p->dec_method[index]; }
+int ambi_dec_getDecEnableMaxrE(void* const hAmbi, int index) { PD; return p->rE_WEIGHT[index]; }
+int ambi_dec_getDecNormType(void* const hAmbi, int index) { PD; return p->diffEQmode[index]; }
+float ambi_dec_getTransitionFreq(void* const hAmbi) { PD; return p->transitionFreq; }
+int ambi_dec_getHRIRsamplerate(void* const hAmbi) { PD; return p->hrir_fs; }
+int ambi_dec_getDAWsamplerate(void* const hAmbi) { PD; return p->fs; }
+int ambi_dec_getProcessingDelay(void) { return 12 * SAF_HOP; }
+
+void saf_hip_ambi_dec_getDecoderMtx(void* const hAmbi, int decIdx, int order, int maxrE, float* out)
+{
+    PD;
+    const std::vector<float>& M = maxrE ? p->M_dec_maxrE[decIdx][order - 1] : p->M_dec[decIdx][order - 1];
+    memcpy(out, M.data(), sizeof(float) * M.size());
+}
+float saf_hip_ambi_dec_getDecoderNorm(void* const hAmbi, int decIdx, int order, int ampOrEnergy) { PD; return p->M_norm[decIdx][order - 1][ampOrEnergy]; }
+
+/* ------------------------------- batched entry point ------------------------------- */
+void* saf_hip_ambi_dec_batch_create(void* const* hAmbis, int nInst, int maxFramesPerCall)
+{
+    if (nInst <= 0 || maxFramesPerCall <= 0) SAF_FATAL("ambi_dec batch: nInst and maxFramesPerCall must be positive");
+    ensure_device();
+    DecPipeline* b = new DecPipeline();
+    b->create((AmbiDec* const*)hAmbis, nInst, maxFramesPerCall);
+    return b;
+}
+void saf_hip_ambi_dec_batch_destroy(void** const phBatch)
+{
+    if (!phBatch || !*phBatch) return;
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    delete (DecPipeline*)*phBatch;
+    *phBatch = nullptr;
+}
+void saf_hip_ambi_dec_batch_clear(void* const hBatch) { ((DecPipeline*)hBatch)->st.clear(); }
+void saf_hip_ambi_dec_batch_process(void* const hBatch,
+                                    const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride,
+                                    float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride,
+                                    int nFrames)
+{
+    DecPipeline* b = (DecPipeline*)hBatch;
+    b->process(d_in, in_inst_stride, in_frame_stride, in_ch_stride, b->nSH < 4 ? 4 : b->nSH,
+               d_out, out_inst_stride, out_frame_stride, out_ch_stride, nFrames);
+}
+
+}  // extern "C"

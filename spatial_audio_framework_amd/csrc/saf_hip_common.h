@@ -1,0 +1,149 @@
+/*
+ * saf_hip_common.h — internal helpers shared by the libsaf_hip translation units.
+ * (Not part of the public C-ABI; see include/saf_hip.h for that.)
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+
+#define SAF_HOP        128          /* afSTFT hop size of all operators (ambi_dec_internal.h:68) */
+#define SAF_NBINS      129
+#define SAF_NBANDS     133          /* hybrid bands (ambi_dec_internal.h:69) */
+#define SAF_MAXCH      64           /* MAX_NUM_CHANNELS (_common.h:228) */
+#define SAF_MAX_ORDER  7            /* MAX_SH_ORDER (_common.h:50) */
+#define SAF_ANA_HIST   15           /* input hops of history the analysis kernel needs (9 window + 6 hybrid) */
+#define SAF_SYN_HIST   9            /* synthesised frames of history the overlap-add needs */
+
+#define SAF_PI   3.14159265358979323846264338327950288f
+#define SAF_PId  3.14159265358979323846264338327950288
+#define SAF_SQRT4PI 3.544907701811032f
+#define ORDER2NSH(o) (((o) + 1) * ((o) + 1))
+
+/* The product has no CPU fallback: any HIP failure is fatal and loud. */
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            fprintf(stderr, "libsaf_hip: HIP error %s (%d) at %s:%d: %s\n", hipGetErrorString(e_),  \
+                    (int)e_, __FILE__, __LINE__, #expr);                                             \
+            abort();                                                                                 \
+        }                                                                                            \
+    } while (0)
+
+#define SAF_FATAL(...)                                                   \
+    do {                                                                 \
+        fprintf(stderr, "libsaf_hip: " __VA_ARGS__);                    \
+        fprintf(stderr, "\n");                                           \
+        abort();                                                         \
+    } while (0)
+
+namespace saf {
+
+/* ---- runtime (runtime.cpp) ---- */
+hipStream_t stream();                 /* stream all library work is enqueued on */
+void        set_stream(hipStream_t);  /* adopt a caller's stream (e.g. torch's current stream) */
+void        ensure_device();          /* aborts with a clear message when no GPU is usable */
+
+/* ---- optional per-kernel timing with HIP events on the library stream (runtime.cpp) ---- */
+struct KernelTimer {            /* RAII: brackets one kernel launch when profiling is enabled */
+    explicit KernelTimer(const char* name);
+    ~KernelTimer();
+    int slot;
+};
+
+/* ---- data tables (tables.cpp) ---- */
+const float* table(const char* name, int* d0, int* d1);   /* host pointer, NULL if absent */
+const float* table_required(const char* name, int d0);
+
+/* ---- constant device tables shared by the afSTFT kernels (afstft_kernels.hip) ---- */
+const float*  dev_window(int lowDelay, int synthesis);   /* [1280] */
+const float2* dev_twiddles();                            /* [8][64] */
+
+/* simple owning device buffer */
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count, bool zero = true) {
+        release();
+        n = count;
+        if (!count) return;
+        HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
+        if (zero) HIP_CHECK(hipMemsetAsync(p, 0, count * sizeof(T), stream()));
+    }
+    void zero() { if (p) HIP_CHECK(hipMemsetAsync(p, 0, n * sizeof(T), stream())); }
+    void release() { if (p) { HIP_CHECK(hipFree(p)); p = nullptr; n = 0; } }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+/* pinned host staging buffer */
+template <typename T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void ensure(size_t count) {
+        if (count <= n) return;
+        if (p) HIP_CHECK(hipHostFree(p));
+        HIP_CHECK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        n = count;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+};
+
+/* ---- afSTFT device core (afstft_kernels.hip) ---- */
+struct AnaLaunch {
+    const float* in;            /* samples: in[inst*in_inst + frame*in_frame + ch*in_ch + (hop%T)*128 + n] */
+    long long in_inst, in_ch, in_frame;
+    int hopsPerFrame;           /* T */
+    int nChIn;                  /* channels physically present in `in`; the rest are zero */
+    const float* hist_rd;       /* [inst][nCh][15][128] */
+    float* hist_wr;
+    float2* out;                /* spectra out[inst*out_inst + band*out_band + ch*out_ch + hop] */
+    long long out_inst, out_band, out_ch;
+    const float* ch_scale;      /* [nInst][nCh] or null */
+    const int* ch_map;          /* [nInst][nCh] input channel gather map or null */
+    int tab_stride;             /* instance stride of ch_scale / ch_map (0: nCh) */
+    int nCh, nInst, H;          /* H = hops in this launch */
+    int lowDelay, hybrid;
+};
+void launch_analysis(const AnaLaunch& a);
+
+struct SynLaunch {
+    const float2* in;           /* spectra in[inst*in_inst + band*in_band + ch*in_ch + hop] */
+    long long in_inst, in_band, in_ch;
+    float* out;                 /* samples, addressed like AnaLaunch::in */
+    long long out_inst, out_ch, out_frame;
+    int hopsPerFrame;
+    const float* hist_rd;       /* [inst][nCh][9][256] */
+    float* hist_wr;
+    int nCh, nInst, H;
+    int lowDelay, hybrid;
+};
+void launch_synthesis(const SynLaunch& s);
+
+/* ---- band-batched real GEMM on MFMA (gemm_kernels.hip) ----
+ * For every (inst, band): Y[64 x N] = A[mat(inst,band)][64 x 64] * X[64 x N], N = 2*H floats
+ * (interleaved re/im of H time slots).  A is stored in MFMA fragment order, see pack_A(). */
+struct BandGemmLaunch {
+    const float* X; long long x_inst, x_band, x_row;      /* float strides */
+    float* Y;       long long y_inst, y_band, y_row;
+    const float* Afrag;            /* [nInst][nMat][2][32][64] */
+    long long a_inst;              /* float stride between instances' matrix sets */
+    const int* band2mat;           /* [nInst][nBands] */
+    int nBands, nInst, N;
+};
+void launch_band_gemm(const BandGemmLaunch& g);
+void pack_A(const float* A /* [64][64] row-major, zero padded */, float* Afrag /* [2][32][64] */);
+
+}  // namespace saf

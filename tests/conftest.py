@@ -1,0 +1,31 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+for p_ in (ROOT, ROOT / "tests", ROOT / "tests" / "golden"):
+    if str(p_) not in sys.path:
+        sys.path.insert(0, str(p_))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure only)."""
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def saf():
+    """The product API (libsaf_hip.so through ctypes). Fails loudly if the library is missing."""
+    from spatial_audio_framework_amd import api
+    from spatial_audio_framework_amd._lib import load
+    load()
+    return api

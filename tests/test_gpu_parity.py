@@ -1,0 +1,389 @@
+"""Parity of the HIP path (libsaf_hip.so, called through its C-ABI) with the CPU
+oracle — needs an MI355X:  python -m pytest tests -m gpu
+
+Tolerance: BASELINE.json / SURVEY §8d ask for <= 1e-5 relative RMS against the
+reference CPU path for floating-point outputs and bit-exact triangulation
+indices.  The asserts below use TOL = 1e-5 where the north star states it and
+tighter bounds (a few float32 ulps) where the algorithm allows.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from util import frames, relrms, maxabs, canon_faces
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5          # north_star: "output within 1e-5 RMS of reference"
+GOLD = Path(__file__).parent / "golden"
+
+
+def tdesign(orc, degree):
+    return orc.table(f"Tdesign_degree_{degree}_dirs_deg")
+
+
+# ------------------------------------------------------------------ afSTFT
+def test_afSTFT_forward_backward_vs_oracle(saf, orc):
+    nin, nout, F = 7, 5, 512
+    g, o = saf.AfSTFT(nin, nout), orc.AfSTFT(nin, nout)
+    assert (g.nBands, g.delay) == (o.nBands, o.delay) == (133, 1536)
+    rng = np.random.default_rng(0)
+    for fr in range(8):
+        x = frames(10 + fr, nin, F)
+        assert relrms(g.forward(x), o.forward(x)) < 1e-6
+        Y = (rng.normal(size=(133, nout, 4)) + 1j * rng.normal(size=(133, nout, 4))).astype(np.complex64)
+        assert relrms(g.backward(Y), o.backward(Y)) < 1e-6
+    assert np.allclose(g.centreFreqs(48000.0), o.centreFreqs(48000.0), rtol=0, atol=0)
+    assert np.array_equal(saf.afSTFT_getCentreFreqs_nullHandle(44100.0), orc.centreFreqs_nullHandle(44100.0))
+
+
+def test_afSTFT_reference_unit_test_on_gpu(saf):
+    """test__afSTFT (test/src/test__resources.c:27-100) against the HIP filterbank."""
+    F, nin, nout = 512, 60, 64
+    L = 24000
+    x = frames(11, nin, L)
+    st = saf.AfSTFT(nin, nout)
+    st.channelChange(100, 5); st.clearBuffers(); st.channelChange(39, 81); st.channelChange(nin, nout); st.clearBuffers()
+    out = np.zeros((nout, L), np.float32)
+    for fr in range(L // F):
+        S = st.forward(x[:, fr * F:(fr + 1) * F])
+        out[:, fr * F:(fr + 1) * F] = st.backward(np.ascontiguousarray(np.repeat(S[:, 0:1, :], nout, axis=1)))
+    n = (L // F) * F - st.delay - F
+    assert np.abs(x[0, :n] - out[0, st.delay:st.delay + n]).max() <= 0.01
+
+
+def test_afSTFT_channelChange_keeps_surviving_state(saf, orc):
+    g, o = saf.AfSTFT(4, 4), orc.AfSTFT(4, 4)
+    x = frames(1, 4, 512)
+    g.forward(x); o.forward(x)
+    g.channelChange(6, 2); o.channelChange(6, 2)           # channels 0..3 keep their history, 4..5 start from zero
+    x2 = frames(2, 6, 256)
+    assert relrms(g.forward(x2), o.forward(x2)) < 1e-6
+    Y = (frames(3, 133 * 2 * 2, 2)[:, 0] + 1j * frames(3, 133 * 2 * 2, 2)[:, 1]).reshape(133, 2, 2).astype(np.complex64)
+    assert relrms(g.backward(Y), o.backward(Y)) < 1e-6
+    g.clearBuffers(); o.clearBuffers()
+    assert relrms(g.forward(x2), o.forward(x2)) < 1e-6
+
+
+def test_afSTFT_knownDimensions_layout_and_untouched_padding(saf, orc):
+    """afSTFT_forward_knownDimensions (afSTFTlib.c:267-308): band stride dataFD_nCH*dataFD_nHops, rows beyond nCHin untouched."""
+    g, o = saf.AfSTFT(3, 1), orc.AfSTFT(3, 1)
+    x = frames(8, 3, 256)
+    A = g.forward_knownDimensions(x, 64, 2)
+    B = o.forward(x, nCH_alloc=64)
+    assert A.shape == (133, 64, 2) and relrms(A[:, :3], B[:, :3]) < 1e-6
+    assert not A[:, 3:].any()
+
+
+def test_afSTFT_split_invariance_and_long_launch(saf, orc):
+    """One 40-hop call == 2 + 22 + 16 hop calls (device state carries over); also exercises the time-chunked grid."""
+    x = frames(5, 2, 40 * 128)
+    a, b, o = saf.AfSTFT(2, 2), saf.AfSTFT(2, 2), orc.AfSTFT(2, 2)
+    A = a.forward(x)
+    B = np.concatenate([b.forward(x[:, :256]), b.forward(x[:, 256:24 * 128]), b.forward(x[:, 24 * 128:])], axis=2)
+    assert np.array_equal(A, B)
+    assert relrms(A, o.forward(x)) < 1e-6
+    ya = a.backward(A)
+    yb = np.concatenate([b.backward(np.ascontiguousarray(A[:, :, :7])), b.backward(np.ascontiguousarray(A[:, :, 7:]))], axis=1)
+    assert np.array_equal(ya, yb)
+    assert relrms(ya, o.backward(A)) < 1e-6
+
+
+def test_afSTFT_nonhybrid_and_lowdelay_modes(saf, orc):
+    for ld, hyb in ((0, 0), (1, 1), (1, 0)):
+        g, o = saf.AfSTFT(2, 2, 128, ld, hyb), orc.AfSTFT(2, 2, 128, ld, hyb)
+        assert g.nBands == o.nBands and g.delay == o.delay
+        for fr in range(4):
+            x = frames(40 + fr, 2, 384)
+            Xg, Xo = g.forward(x), o.forward(x)
+            assert relrms(Xg, Xo) < 1e-6
+            assert relrms(g.backward(Xo), o.backward(Xo)) < 1e-6
+
+
+def test_afSTFT_time_ch_bands_format(saf, orc):
+    g = saf.AfSTFT(2, 2, fmt=saf.AFSTFT_TIME_CH_BANDS)
+    o = orc.AfSTFT(2, 2)
+    x = frames(77, 2, 384)
+    A = g.forward(x)                                  # [t][ch][band]
+    assert relrms(A.transpose(2, 1, 0), o.forward(x)) < 1e-6
+
+
+def test_afSTFT_device_pointer_entry(saf, orc):
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    nch, nH = 3, 12
+    x = frames(6, nch, nH * 128)
+    d_x = torch.from_numpy(x).cuda()
+    d_X = torch.zeros(133, nch, nH, dtype=torch.complex64, device="cuda")
+    g, o = saf.AfSTFT(nch, nch), orc.AfSTFT(nch, nch)
+    g.forward_dev(d_x.data_ptr(), nH * 128, nH, d_X.data_ptr(), nch * nH, nH)
+    d_y = torch.zeros(nch, nH * 128, device="cuda")
+    g.backward_dev(d_X.data_ptr(), nch * nH, nH, nH, d_y.data_ptr(), nH * 128)
+    torch.cuda.synchronize()
+    Xo = o.forward(x)
+    assert relrms(d_X.cpu().numpy(), Xo) < 1e-6
+    assert relrms(d_y.cpu().numpy(), o.backward(Xo)) < 1e-6
+    saf.set_stream(None)
+
+
+def test_FIRtoFilterbankCoeffs_vs_oracle(saf, orc):
+    rng = np.random.default_rng(2)
+    ir = (rng.normal(size=(5, 2, 200)) * np.exp(-np.arange(200) / 30.0)).astype(np.float32)
+    ir[:, :, 20] += 1.0
+    A, B = saf.afSTFT_FIRtoFilterbankCoeffs(ir), orc.FIRtoFilterbankCoeffs(ir)
+    assert relrms(A, B) < 5e-6
+
+
+def test_golden_afstft(saf):
+    ref = np.load(GOLD / "afstft_small.npz")
+    st = saf.AfSTFT(3, 2)
+    x = frames(101, 3, 6 * 256)
+    specs = [st.forward(x[:, i * 256:(i + 1) * 256]) for i in range(6)]
+    y = np.concatenate([st.backward(np.ascontiguousarray(s[:, :2, :])) for s in specs], 1)
+    assert relrms(specs[-1], ref["spec_last"]) < 1e-6 and relrms(y, ref["synth"]) < 1e-6
+
+
+# ------------------------------------------------------------------ SH / HOA / VBAP
+def test_SH_vs_oracle(saf, orc):
+    rng = np.random.default_rng(4)
+    deg = np.stack([rng.uniform(-180, 180, 300), rng.uniform(-90, 90, 300)], 1).astype(np.float32)
+    rad = np.stack([rng.uniform(-np.pi, np.pi, 300), rng.uniform(0, np.pi, 300)], 1).astype(np.float32)
+    for order in (1, 3, 7, 10, 15):
+        s = 4.0 * np.finfo(np.float32).eps * (2 * order + 1)       # a few ulps of the largest SH value
+        assert maxabs(saf.getRSH(order, deg), orc.getRSH(order, deg)) <= s
+        assert maxabs(saf.getSHreal(order, rad), orc.getSHreal(order, rad)) <= s
+        # float32 recursion: device sinf/cosf/powf differ from glibc in the last ulp and the recursion amplifies that
+        assert maxabs(saf.getRSH_recur(order, deg), orc.getRSH_recur(order, deg)) <= 3e-6 * (order + 1) ** 2
+        assert maxabs(saf.getSHreal_recur(order, rad), orc.getSHreal_recur(order, rad)) <= 1e-6 * (order + 1) ** 2
+    # poles and the single-direction case
+    for d in ([[0.0, 90.0]], [[12.0, -90.0]], [[180.0, 0.0]]):
+        assert maxabs(saf.getRSH(7, d), orc.getRSH(7, d)) <= 1e-6
+        assert maxabs(saf.getRSH_recur(7, d), orc.getRSH_recur(7, d)) <= 1e-5
+    assert np.array_equal(saf.getMaxREweights(7), orc.getMaxREweights(7))
+    assert np.array_equal(saf.getMaxREweights(3, True), orc.getMaxREweights(3, True))
+
+
+@pytest.mark.parametrize("order", [1, 2, 4, 7, 10])
+def test_reference_SH_and_decoder_properties_on_gpu(saf, orc, order):
+    """test__getSHreal (test__sh_module.c:27-82) and test__getLoudspeakerDecoderMtx (test__hoa_module.c:27-104) on the HIP build."""
+    ls = tdesign(orc, 2 * order)
+    nLS, nSH = len(ls), (order + 1) ** 2
+    rad = np.stack([ls[:, 0] * np.pi / 180, np.pi / 2 - ls[:, 1] * np.pi / 180], 1).astype(np.float32)
+    Y = saf.getSHreal(order, rad)
+    assert np.abs((Y @ Y.T) * (4 * np.pi / nLS) - np.eye(nSH)).max() <= 1e-5
+    S, M, E, A = (saf.getLoudspeakerDecoderMtx(ls, m, order) for m in (1, 2, 3, 4))
+    assert maxabs(S, M) <= 1e-5 and maxabs(S, E) <= 1e-5
+    LS = E @ Y
+    assert np.abs(LS.sum(0) - 1).max() <= 1e-5 and np.abs((LS ** 2).sum(0) - nSH / nLS).max() <= 1e-5
+
+
+@pytest.mark.parametrize("layout,order", [("SphCovering_64_dirs_deg", 7), ("SphCovering_49_dirs_deg", 6), ("Tdesign_degree_10_dirs_deg", 5), ("22pX_dirs_deg", 3)])
+def test_decoder_matrices_vs_oracle(saf, orc, layout, order):
+    ls = orc.table(layout)
+    for method in (1, 2, 3, 4):
+        for maxre in (0, 1):
+            A = saf.getLoudspeakerDecoderMtx(ls, method, order, maxre)
+            B = orc.getLoudspeakerDecoderMtx(ls, method, order, maxre)
+            assert maxabs(A, B) <= 2e-6, (layout, method)
+
+
+@pytest.mark.parametrize("layout", ["SphCovering_64_dirs_deg", "SphCovering_49_dirs_deg", "Tdesign_degree_10_dirs_deg", "SphCovering_9_dirs_deg"])
+def test_triangulation_indices_bit_exact(saf, orc, layout):
+    """Bit-exact VBAP triangulation indices on layouts where the reference itself is deterministic:
+    compared as canonically sorted face sets."""
+    ls = orc.table(layout)
+    Vg, Fg = saf.findLsTriplets(ls)
+    Vo, Fo = orc.findLsTriplets(ls)
+    assert np.array_equal(Vg, Vo)
+    assert np.array_equal(canon_faces(Fg), canon_faces(Fo))
+    assert len(Fg) == 2 * len(ls) - 4
+
+
+def test_vbap_tables_vs_oracle(saf, orc):
+    ls = orc.table("SphCovering_25_dirs_deg")
+    rng = np.random.default_rng(6)
+    src = np.stack([rng.uniform(-180, 180, 500), rng.uniform(-90, 90, 500)], 1).astype(np.float32)
+    for spread in (0.0, 30.0):
+        Gg, ng = saf.generateVBAPgainTable3D_srcs(src, ls, 0, 0, spread)
+        Go, no = orc.generateVBAPgainTable3D_srcs(src, ls, 0, 0, spread)
+        assert ng == no and maxabs(Gg, Go) <= 2e-6
+    half = ls[ls[:, 1] > -10]                                     # needs a dummy loudspeaker below
+    Gg, _ = saf.generateVBAPgainTable3D(half, 5, 5, 1, 1, 0.0)
+    Go, _ = orc.generateVBAPgainTable3D(half, 5, 5, 1, 1, 0.0)
+    assert Gg.shape == Go.shape == (73 * 37, len(half)) and maxabs(Gg, Go) <= 2e-6
+    cg, ig = saf.compressVBAPgainTable3D(Gg)
+    co, io = orc.compressVBAPgainTable3D(Go)
+    assert np.array_equal(ig, io) and maxabs(cg, co) <= 2e-6
+
+
+def test_golden_sh_decoders(saf, orc):
+    ref = np.load(GOLD / "sh_decoders_small.npz")
+    ls = orc.table("SphCovering_9_dirs_deg")
+    assert maxabs(saf.getRSH(3, ls), ref["rsh"]) <= 1e-6 and maxabs(saf.getRSH_recur(3, ls), ref["rsh_recur"]) <= 1e-5
+    for m, k in ((1, "sad"), (2, "mmd"), (3, "epad"), (4, "allrad")):
+        assert maxabs(saf.getLoudspeakerDecoderMtx(ls, m, 2), ref[k]) <= 2e-6
+    assert np.array_equal(canon_faces(saf.findLsTriplets(ls)[1]), canon_faces(ref["faces"]))
+
+
+# ------------------------------------------------------------------ ambi_dec
+def mk(cls, F, order, preset, m0, m1, norm=1, low_order=None, **kw):
+    a = cls(F)
+    a.setNormType(norm); a.setChOrder(1); a.setMasterDecOrder(order); a.setOutputConfigPreset(preset)
+    a.setDecMethod(0, m0); a.setDecMethod(1, m1)
+    a.initCodec(); a.init(48000); a.setDecOrderAllBands(order)
+    if low_order:
+        for b in range(40, 133):
+            a.setDecOrder(low_order, b)
+    for k, v in kw.items():
+        getattr(a, k)(*v)
+    return a
+
+
+def run(dec, x, nOut, F):
+    return np.concatenate([dec.process(np.ascontiguousarray(x[:, i * F:(i + 1) * F]), nOut) for i in range(x.shape[1] // F)], 1)
+
+
+def test_ambi_dec_headline_config_vs_oracle(saf, orc):
+    """BASELINE config 2: order 7, 64 SH -> 64 loudspeakers (SphCovering-64), 512-sample blocks, SAD, maxrE, energy-preserving."""
+    g, o = mk(saf.AmbiDec, 512, 7, 29, 1, 1), mk(orc.AmbiDec, 512, 7, 29, 1, 1)
+    x = frames(1, 64, 12 * 512)
+    yg, yo = run(g, x, 64, 512), run(o, x, 64, 512)
+    assert relrms(yg[:, 1536:], yo[:, 1536:]) < TOL
+    assert relrms(yg, yo) < 1e-6 and maxabs(yg, yo) < 2e-6
+    for dec in (0, 1):
+        assert np.array_equal(g.decMtx(dec, 7, 1, 64), o.decMtx(dec, 7, 1, 64))
+        assert abs(g.Mnorm(dec, 7, 1) - o.Mnorm(dec, 7, 1)) < 1e-6
+
+
+@pytest.mark.parametrize("m0,m1,norm,low", [(1, 3, 2, 3), (4, 2, 1, 2), (3, 4, 2, None)])
+def test_ambi_dec_mixed_decoders_orders_norms(saf, orc, m0, m1, norm, low):
+    """SURVEY Appendix D scenario: different decoders below/above the transition, lower order above band 40, SN3D input."""
+    kw = dict(setDecNormType=(0, 1), setDecEnableMaxrE=(1, 0), setTransitionFreq=(1200.0,))
+    g = mk(saf.AmbiDec, 256, 5, 28, m0, m1, norm, low, **kw)
+    o = mk(orc.AmbiDec, 256, 5, 28, m0, m1, norm, low, **kw)
+    x = frames(3, 36, 14 * 256)
+    yg, yo = run(g, x, 49, 256), run(o, x, 49, 256)
+    assert relrms(yg, yo) < TOL and relrms(yg, yo) < 2e-6
+    # parameters changed on the fly are picked up at the next block (snapshot at block start, ambi_dec.c:479-488)
+    for d in (g, o):
+        d.setDecEnableMaxrE(0, 0); d.setDecNormType(1, 1); d.setDecOrderAllBands(2); d.setTransitionFreq(700.0)
+    x2 = frames(4, 36, 4 * 256)
+    assert relrms(run(g, x2, 49, 256), run(o, x2, 49, 256)) < 2e-6
+
+
+def test_ambi_dec_fuma_first_order_and_missing_channels(saf, orc):
+    def cfg(cls):
+        a = cls(128)
+        a.setMasterDecOrder(1); a.setChOrder(2); a.setNormType(3); a.setOutputConfigPreset(3)      # FuMa/FuMa into 5.x (2-D layout)
+        a.setDecMethod(0, 1); a.setDecMethod(1, 4)
+        a.initCodec(); a.init(44100)
+        return a
+    g, o = cfg(saf.AmbiDec), cfg(orc.AmbiDec)
+    x = frames(9, 4, 10 * 128)
+    assert relrms(run(g, x, 5, 128), run(o, x, 5, 128)) < 2e-6
+    x3 = frames(10, 3, 4 * 128)                       # only 3 of 4 inputs supplied -> the 4th is zero; 7 outputs asked -> 2 zeroed
+    yg, yo = run(g, x3, 7, 128), run(o, x3, 7, 128)
+    assert relrms(yg, yo) < 2e-6 and not yg[5:].any()
+
+
+def test_ambi_dec_reference_example_test_on_gpu(saf):
+    """test__saf_example_ambi_dec (test/src/test__examples.c:109-190), incl. its swapped setDecMethod arguments."""
+    d = saf.AmbiDec(128)
+    d.setNormType(1); d.setMasterDecOrder(4); d.setOutputConfigPreset(saf.LOUDSPEAKER_ARRAY_PRESET_22PX)
+    d.setDecMethod(saf.DECODING_METHOD_SAD, 0); d.setDecMethod(saf.DECODING_METHOD_SAD, 1)
+    d.initCodec(); d.init(48000)
+    L = 128 * 100
+    sh = saf.getRSH(4, [[90.0, 0.0]]) @ frames(4, 1, L)
+    out = run(d, sh.astype(np.float32), 22, 128)
+    assert int((out ** 2).sum(1).argmax()) == 7
+
+
+def test_ambi_dec_zero_output_rules(saf):
+    d = saf.AmbiDec(256)
+    d.setMasterDecOrder(2); d.setOutputConfigPreset(25); d.setDecMethod(0, 1); d.setDecMethod(1, 1)
+    x = frames(1, 9, 256)
+    assert not d.process(x, 9).any()                                 # not initialised
+    d.initCodec(); d.init(48000)
+    assert d.process(x, 9).any()
+    assert not d.process(x[:, :128], 9, nSamples=128).any()          # wrong block size
+    d.setMasterDecOrder(3)                                           # invalidates the codec
+    assert d.getCodecStatus() == saf.CODEC_STATUS_NOT_INITIALISED and not d.process(x, 9).any()
+    d.initCodec()
+    y = d.process(frames(2, 16, 256), 9)
+    assert y.any() and d.getNSHrequired() == 16
+
+
+def test_golden_ambi_dec(saf):
+    from make_golden import ambi_dec_cfg
+    ref = np.load(GOLD / "ambi_dec_small.npz")
+    d = ambi_dec_cfg(saf.AmbiDec, 128, 3, 26, 1, 3, low_order=1)
+    assert relrms(run(d, frames(202, 16, 6 * 128), 16, 128), ref["out"]) < 2e-6
+
+
+def test_ambi_dec_batch_equals_single_instances(saf, orc):
+    """saf_hip_ambi_dec_batch_process: 3 instances with DIFFERENT decoders x 2 calls of 5 blocks, strided device buffers."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    cfgs = [(1, 1, 1, None), (3, 2, 2, 3), (4, 1, 1, 5)]
+    decs = [mk(saf.AmbiDec, 512, 7, 29, a, b, n, lo) for a, b, n, lo in cfgs]
+    orcs = [mk(orc.AmbiDec, 512, 7, 29, a, b, n, lo) for a, b, n, lo in cfgs]
+    nI, nF = 3, 5
+    bt = saf.AmbiDecBatch(decs, nF)
+    x = np.stack([frames(50 + i, 2 * nF * 64, 512).reshape(2 * nF, 64, 512) for i in range(nI)])
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.zeros(nI, 2 * nF, 64, 512, device="cuda")
+    st = (2 * nF * 64 * 512, 64 * 512, 512)
+    for call in range(2):
+        bt.process_ptr(d_in[:, call * nF:].data_ptr(), st, d_out[:, call * nF:].data_ptr(), st, nF)
+    torch.cuda.synchronize()
+    yg = d_out.cpu().numpy()
+    for i in range(nI):
+        yo = np.stack([orcs[i].process(x[i, f], 64) for f in range(2 * nF)])
+        assert relrms(yg[i], yo) < 2e-6, i
+    # channel-major layout [inst][ch][time] through strides, continuing the same streams
+    x2 = np.stack([frames(70 + i, 64, nF * 512) for i in range(nI)])
+    d_in2 = torch.from_numpy(x2).cuda(); d_out2 = torch.zeros_like(d_in2)
+    st2 = (64 * nF * 512, 512, nF * 512)
+    bt.process_ptr(d_in2.data_ptr(), st2, d_out2.data_ptr(), st2, nF)
+    torch.cuda.synchronize()
+    for i in range(nI):
+        yo = np.concatenate([orcs[i].process(np.ascontiguousarray(x2[i][:, f * 512:(f + 1) * 512]), 64) for f in range(nF)], 1)
+        assert relrms(d_out2[i].cpu().numpy(), yo) < 2e-6
+    saf.set_stream(None)
+
+
+def test_ambi_dec_full_size_properties(saf):
+    """At BASELINE size (64 instances x 16 blocks per call) the oracle is too slow to run everywhere, so check
+    size-independent properties: linearity, instance independence, agreement of two different batch splits."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    nI, nF = 64, 16
+    decs = [mk(saf.AmbiDec, 512, 7, 29, 1, 1) for _ in range(nI)]
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    a = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+    b = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+    st = (nF * 64 * 512, 64 * 512, 512)
+
+    def go(x, split=None):
+        bt = saf.AmbiDecBatch(decs, nF)
+        y = torch.zeros_like(x)
+        if split is None:
+            bt.process_ptr(x.data_ptr(), st, y.data_ptr(), st, nF)
+        else:
+            f0 = 0
+            for n in split:
+                bt.process_ptr(x[:, f0:].data_ptr(), st, y[:, f0:].data_ptr(), st, n)
+                f0 += n
+        torch.cuda.synchronize()
+        return y
+
+    ya, yb, yab = go(a), go(b), go(2.0 * a - 0.5 * b)
+    lin = 2.0 * ya - 0.5 * yb
+    assert float((yab - lin).norm() / lin.norm()) < 1e-6                    # linearity
+    assert torch.equal(go(a, split=(1, 7, 8)), ya)                          # state carried across calls, bit-identical
+    a2 = a.clone(); a2[5] = b[5]
+    y2 = go(a2)
+    assert torch.equal(y2[:5], ya[:5]) and torch.equal(y2[6:], ya[6:]) and torch.equal(y2[5], yb[5])   # instances independent
+    assert torch.equal(ya[0], go(a[:1].contiguous().expand(nI, -1, -1, -1).contiguous())[17])          # same input -> same output
+    saf.set_stream(None)
