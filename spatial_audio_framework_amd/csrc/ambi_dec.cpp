@@ -96,8 +96,10 @@ struct DecPipeline {
             if (inst[i]->binauraliseLS) SAF_FATAL("ambi_dec batch: binauralised output is not implemented in this build");
         }
         st.create(nInst, nSH, nLS);
-        X.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, false);
-        Y.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, false);
+        /* zeroed once: the analysis only ever writes the first nSH channel rows, the GEMM reads all 64
+         * (against zero matrix columns) — stale NaNs there would poison the product */
+        X.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);
+        Y.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);
         Afrag.alloc((size_t)nInst * NMAT * 64 * 64);
         band2mat.alloc((size_t)nInst * SAF_NBANDS);
         chScale.alloc((size_t)nInst * SAF_MAXCH);

@@ -32,10 +32,10 @@ def ambi_dec_cfg(cls, F, order, preset, m0, m1, low_order=None):
 
 def generate(O):
     out = {}
-    # afSTFT: 3 in / 2 out, 6 frames of 256 with carried state; spectra of the last frame + synthesised signal
+    # afSTFT: 3 in / 2 out, 12 frames of 256 with carried state; spectra of the last frame + synthesised signal
     st = O.AfSTFT(3, 2)
-    x = frames(101, 3, 6 * 256)
-    specs = [st.forward(x[:, i * 256:(i + 1) * 256]) for i in range(6)]
+    x = frames(101, 3, 12 * 256)
+    specs = [st.forward(x[:, i * 256:(i + 1) * 256]) for i in range(12)]
     y = np.concatenate([st.backward(s[:, :2, :]) for s in specs], 1)
     out["afstft_small"] = {"spec_last": specs[-1], "synth": y}
     # SH + decoders on SphCovering-9, order 2
@@ -48,8 +48,8 @@ def generate(O):
     }
     # ambi_dec order 3 -> t-design(60)... use SphCovering-16, mixed decoders + per-band orders, 6 frames of 128
     d = ambi_dec_cfg(O.AmbiDec, 128, 3, 26, 1, 3, low_order=1)
-    xin = frames(202, 16, 6 * 128)
-    yo = np.concatenate([d.process(xin[:, i * 128:(i + 1) * 128], 16) for i in range(6)], 1)
+    xin = frames(202, 16, 24 * 128)
+    yo = np.concatenate([d.process(xin[:, i * 128:(i + 1) * 128], 16) for i in range(24)], 1)
     out["ambi_dec_small"] = {"out": yo}
     # matrixConv 3 -> 2, 96 taps, hop 64, 5 blocks
     H = (np.random.default_rng(5).normal(size=(2, 3, 96)) / 8).astype(np.float32)
