@@ -228,6 +228,53 @@ SAF_API void  saf_hip_ambi_dec_batch_process(void* const hBatch,
                                              float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride,
                                              int nFrames);
 
+/* ========================================================================== */
+/*      ambi_enc (examples/include/ambi_enc.h:55-222)                         */
+/* ========================================================================== */
+/** The reference fixes the block size at compile time (-DAMBI_ENC_FRAME_SIZE, ambi_enc_internal.h:41-47, default 64).
+ *  Here it is a process-wide setting read by ambi_enc_create; must be a multiple of 4. */
+SAF_API void saf_hip_ambi_enc_setFrameSize(int frameSize);
+
+SAF_API void ambi_enc_create(void** const phAmbi);                               /* ambi_enc.h:55 */
+SAF_API void ambi_enc_destroy(void** const phAmbi);                              /* ambi_enc.h:62 */
+SAF_API void ambi_enc_init(void* const hAmbi, int samplerate);                   /* ambi_enc.h:70 */
+SAF_API void ambi_enc_process(void* const hAmbi, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* ambi_enc.h:84 */
+SAF_API void ambi_enc_refreshParams(void* const hAmbi);                          /* ambi_enc.h:100 */
+SAF_API void ambi_enc_setOutputOrder(void* const hAmbi, int newValue);           /* ambi_enc.h:105 */
+SAF_API void ambi_enc_setSourceAzi_deg(void* const hAmbi, int index, float newAzi_deg);    /* ambi_enc.h:114 */
+SAF_API void ambi_enc_setSourceElev_deg(void* const hAmbi, int index, float newElev_deg);  /* ambi_enc.h:123 */
+SAF_API void ambi_enc_setNumSources(void* const hAmbi, int new_nSources);        /* ambi_enc.h:126 */
+SAF_API void ambi_enc_setInputConfigPreset(void* const hAmbi, int newPresetID);  /* ambi_enc.h:129 */
+SAF_API void ambi_enc_setChOrder(void* const hAmbi, int newOrder);               /* ambi_enc.h:135 */
+SAF_API void ambi_enc_setNormType(void* const hAmbi, int newType);               /* ambi_enc.h:141 */
+SAF_API void ambi_enc_setEnablePostScaling(void* const hAmbi, int newStatus);    /* ambi_enc.h:147 */
+SAF_API void ambi_enc_setSourceGain(void* const hAmbi, int srcIdx, float newGain); /* ambi_enc.h:153 */
+SAF_API void ambi_enc_setSourceSolo(void* const hAmbi, int srcIdx);              /* ambi_enc.h:158 */
+SAF_API void ambi_enc_setUnSolo(void* const hAmbi);                              /* ambi_enc.h:163 */
+SAF_API int  ambi_enc_getFrameSize(void);                                        /* ambi_enc.h:174 */
+SAF_API int  ambi_enc_getOutputOrder(void* const hAmbi);                         /* ambi_enc.h:183 */
+SAF_API float ambi_enc_getSourceAzi_deg(void* const hAmbi, int index);           /* ambi_enc.h:186 */
+SAF_API float ambi_enc_getSourceElev_deg(void* const hAmbi, int index);          /* ambi_enc.h:189 */
+SAF_API int  ambi_enc_getNumSources(void* const hAmbi);                          /* ambi_enc.h:192 */
+SAF_API int  ambi_enc_getMaxNumSources(void);                                    /* ambi_enc.h:195 */
+SAF_API int  ambi_enc_getNSHrequired(void* const hAmbi);                         /* ambi_enc.h:201 */
+SAF_API int  ambi_enc_getChOrder(void* const hAmbi);                             /* ambi_enc.h:207 */
+SAF_API int  ambi_enc_getNormType(void* const hAmbi);                            /* ambi_enc.h:213 */
+SAF_API int  ambi_enc_getEnablePostScaling(void* const hAmbi);                   /* ambi_enc.h:216 */
+SAF_API int  ambi_enc_getProcessingDelay(void);                                  /* ambi_enc.h:222 */
+
+/* ---- batched, device-resident entry point: nInst ambi_enc handles with the same block size; one call
+ * encodes nFrames consecutive blocks of every instance (each output block is the encoding of the block
+ * before it, exactly like consecutive ambi_enc_process calls; direction changes made through the set
+ * functions take effect, cross-faded, on the first block of the next call).  Sample addressing as for
+ * saf_hip_ambi_dec_batch_process; `nInputs` / `nOutputs` are the channel rows present in d_in / d_out. */
+SAF_API void* saf_hip_ambi_enc_batch_create(void* const* hAmbis, int nInst, int maxFramesPerCall);
+SAF_API void  saf_hip_ambi_enc_batch_destroy(void** const phBatch);
+SAF_API void  saf_hip_ambi_enc_batch_process(void* const hBatch,
+                                             const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                             float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride, int nOutputs,
+                                             int nFrames);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,5 +122,26 @@ def load():
     sig("saf_hip_ambi_dec_batch_destroy", None, C.POINTER(vp))
     sig("saf_hip_ambi_dec_batch_clear", None, vp)
     sig("saf_hip_ambi_dec_batch_process", None, vp, vp, cll, cll, cll, vp, cll, cll, cll, ci)
+    # ambi_enc
+    sig("saf_hip_ambi_enc_setFrameSize", None, ci)
+    sig("ambi_enc_create", None, C.POINTER(vp))
+    sig("ambi_enc_destroy", None, C.POINTER(vp))
+    sig("ambi_enc_init", None, vp, ci)
+    sig("ambi_enc_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("ambi_enc_refreshParams", None, vp)
+    for n in ("setOutputOrder", "setNumSources", "setInputConfigPreset", "setChOrder", "setNormType", "setEnablePostScaling", "setSourceSolo"):
+        sig("ambi_enc_" + n, None, vp, ci)
+    for n in ("setSourceAzi_deg", "setSourceElev_deg", "setSourceGain"):
+        sig("ambi_enc_" + n, None, vp, ci, cf)
+    sig("ambi_enc_setUnSolo", None, vp)
+    for n in ("getFrameSize", "getMaxNumSources", "getProcessingDelay"):
+        sig("ambi_enc_" + n, ci)
+    for n in ("getOutputOrder", "getNumSources", "getNSHrequired", "getChOrder", "getNormType", "getEnablePostScaling"):
+        sig("ambi_enc_" + n, ci, vp)
+    sig("ambi_enc_getSourceAzi_deg", cf, vp, ci)
+    sig("ambi_enc_getSourceElev_deg", cf, vp, ci)
+    sig("saf_hip_ambi_enc_batch_create", vp, C.POINTER(vp), ci, ci)
+    sig("saf_hip_ambi_enc_batch_destroy", None, C.POINTER(vp))
+    sig("saf_hip_ambi_enc_batch_process", None, vp, vp, cll, cll, cll, ci, vp, cll, cll, cll, ci, ci)
     _lib = L
     return L

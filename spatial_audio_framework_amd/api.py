@@ -261,3 +261,49 @@ class AmbiDecBatch:
     def __del__(self):
         if getattr(self, "hb", None):
             self.L.saf_hip_ambi_dec_batch_destroy(C.byref(self.hb))
+
+
+# ---------------------------------------------------------------- ambi_enc
+class AmbiEnc:
+    """examples/include/ambi_enc.h.  `frameSize` plays the role of -DAMBI_ENC_FRAME_SIZE."""
+
+    def __init__(self, frameSize=64):
+        self.L = load()
+        self.L.saf_hip_ambi_enc_setFrameSize(frameSize)
+        self.h = vp()
+        self.F = frameSize
+        self.L.ambi_enc_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "ambi_enc_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nOut, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.ambi_enc_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ambi_enc_destroy(C.byref(self.h))
+
+
+class AmbiEncBatch:
+    """saf_hip_ambi_enc_batch_*: nInst handles, device-resident blocks."""
+
+    def __init__(self, encoders, maxFramesPerCall):
+        self.L = load()
+        self.encoders = list(encoders)
+        arr = (vp * len(self.encoders))(*[e.h for e in self.encoders])
+        self.nInst = len(self.encoders)
+        self.hb = vp(self.L.saf_hip_ambi_enc_batch_create(arr, self.nInst, maxFramesPerCall))
+
+    def process_ptr(self, d_in, in_strides, nIn, d_out, out_strides, nOut, nFrames):
+        """strides = (inst, frame, ch) in floats."""
+        self.L.saf_hip_ambi_enc_batch_process(self.hb, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nOut, nFrames)
+
+    def __del__(self):
+        if getattr(self, "hb", None):
+            self.L.saf_hip_ambi_enc_batch_destroy(C.byref(self.hb))

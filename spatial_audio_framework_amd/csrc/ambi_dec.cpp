@@ -86,7 +86,8 @@ struct DecPipeline {
     void create(AmbiDec* const* handles, int n, int maxFrames_)
     {
         nInst = n; inst.assign(handles, handles + n);
-        F = inst[0]->F; T = F / SAF_HOP; maxFrames = maxFrames_; Hmax = T * maxFrames;
+        F = inst[0]->F; T = F / SAF_HOP; maxFrames = maxFrames_;
+        Hmax = (T * maxFrames + 15) & ~15;      /* spectra rows are 128-byte multiples: every kernel moves them as 16-byte vectors */
         nSH = ORDER2NSH(inst[0]->masterOrder); nLS = inst[0]->nLoudpkrs;
         for (int i = 0; i < n; i++) {
             if (inst[i]->F != F) SAF_FATAL("ambi_dec batch: all instances must use the same block size");

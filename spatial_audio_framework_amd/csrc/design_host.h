@@ -17,4 +17,5 @@ void maxre_weights(int order, std::vector<float>& a);
 void decoder_matrix(const float* ls_dirs_deg, int nLS, int method, int order, int maxrE, float* dec);
 void sh_eval_host(int kind, int order, const float* dirs, int nDirs, float* Y);
 void sh_eval_dev(int kind, int order, const float* d_dirs, int nDirs, float* d_Y);
+void launch_enc_update_Y(const int* d_order /*[nInst]*/, const float* d_dirs /*[nInst][64][2]*/, const int* d_recalc /*[nInst][64]*/, float* d_Y, long long y_inst, int nInst);
 }  // namespace saf

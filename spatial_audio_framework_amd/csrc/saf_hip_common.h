@@ -145,5 +145,25 @@ struct BandGemmLaunch {
 };
 void launch_band_gemm(const BandGemmLaunch& g);
 void pack_A(const float* A /* [64][64] row-major, zero padded */, float* Afrag /* [2][32][64] */);
+/* device-side pack_A for nMat matrices: A [nMat][64][64] row-major -> Afrag [nMat][2][32][64] */
+void launch_pack_A(const float* d_A, float* d_Afrag, int nMat);
+
+/* ---- SH encode GEMM of ambi_enc (gemm_kernels.hip; ambi_enc.c:138-171) ----
+ * For every (inst, frame f): out = post( fade( Y * p , prevY * p ) ), p = the PREVIOUS frame after its
+ * source gains (frame 0 of a call reads the saved state).  One extra block row saves the last frame. */
+struct EncLaunch {
+    const float* in; long long in_inst, in_frame, in_ch;
+    float* out;      long long out_inst, out_frame, out_ch;
+    const float* prev_rd; float* prev_wr;     /* [nInst][64][F] */
+    const float* Afrag;                       /* [nInst][2 = {Y, prev_Y}][2][32][64] */
+    const float* gains;                       /* [nInst][64] effective per-source gain */
+    const float* postScale;                   /* [nInst] 1/sqrt(nSources) or 1 */
+    const float* rowScale;                    /* [nInst][64] N3D -> output norm, by ACN row */
+    const int* rowMap;                        /* [nInst][64] ACN row -> output channel */
+    const int* nSrc;                          /* [nInst] min(nSources, nInputs present) */
+    const int* mix;                           /* [nInst] 1: frame 0 cross-fades Y with prev_Y; null: nobody mixes */
+    int F, nFrames, nInst, nOut;
+};
+void launch_enc_gemm(const EncLaunch& e);
 
 }  // namespace saf

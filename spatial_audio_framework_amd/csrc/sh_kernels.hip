@@ -121,35 +121,33 @@ __device__ void legendreP_recur_f(int n, float x, const float* Pm1, const float*
     }
 }
 
-/* mode 0: getSHreal_recur (dirs rad, orthonormal incl. 1/sqrt(4pi)); mode 1: getRSH_recur (dirs deg, N3D) */
-__global__ void sh_recur_kernel(int N, const float* dirs, int nDirs, float* Y, int mode)
+/* One direction of getSHreal_recur (mode 0: dirs rad, orthonormal incl. 1/sqrt(4pi)) / getRSH_recur (mode 1: dirs deg,
+ * N3D): writes Y[idx * stride], idx < (N+1)^2 (saf_sh.c:255-331, saf_hoa.c:152-228). */
+__device__ void sh_recur_one(int N, float a, float b, int mode, float* Y, long long stride)
 {
 #pragma clang fp contract(off)
-    const int dir = blockIdx.x * blockDim.x + threadIdx.x;
-    if (dir >= nDirs) return;
     float leg_n[SH_MAX_ORDER + 1], leg_n_1[SH_MAX_ORDER + 1], leg_n_2[SH_MAX_ORDER + 1];
     for (int i = 0; i <= N; i++) leg_n[i] = leg_n_1[i] = leg_n_2[i] = 0.0f;
-    const float a = dirs[dir * 2 + 0], b = dirs[dir * 2 + 1];
     const float ci = mode ? sinf(b * SAF_PI / 180.0f) : cosf(b);
     int index_n = 0;
     for (int n = 0; n < N + 1; n++) {
         if (n == 0) {
-            Y[dir] = mode ? 1.0f : 1.0f / SAF_SQRT4PI;
+            Y[0] = mode ? 1.0f : 1.0f / SAF_SQRT4PI;
             index_n = 1;
         } else {
             legendreP_recur_f(n, ci, leg_n_1, leg_n_2, leg_n);
             const float Nn0 = sqrtf(2.0f * (float)n + 1.0f);
             for (int m = 0; m < n + 1; m++) {
                 if (m == 0) {
-                    Y[(long long)(index_n + n) * nDirs + dir] = mode ? Nn0 * leg_n[m] : Nn0 / SAF_SQRT4PI * leg_n[m];
+                    Y[(long long)(index_n + n) * stride] = mode ? Nn0 * leg_n[m] : Nn0 / SAF_SQRT4PI * leg_n[m];
                 } else {
                     const float Nnm = Nn0 * sqrtf(2.0f * c_fact_f[n - m] / c_fact_f[n + m]);
                     if (mode) {
-                        Y[(long long)(index_n + n - m) * nDirs + dir] = Nnm * leg_n[m] * sinf((float)m * a * SAF_PI / 180.0f);
-                        Y[(long long)(index_n + n + m) * nDirs + dir] = Nnm * leg_n[m] * cosf((float)m * a * SAF_PI / 180.0f);
+                        Y[(long long)(index_n + n - m) * stride] = Nnm * leg_n[m] * sinf((float)m * a * SAF_PI / 180.0f);
+                        Y[(long long)(index_n + n + m) * stride] = Nnm * leg_n[m] * cosf((float)m * a * SAF_PI / 180.0f);
                     } else {
-                        Y[(long long)(index_n + n - m) * nDirs + dir] = Nnm / SAF_SQRT4PI * leg_n[m] * sinf((float)m * a);
-                        Y[(long long)(index_n + n + m) * nDirs + dir] = Nnm / SAF_SQRT4PI * leg_n[m] * cosf((float)m * a);
+                        Y[(long long)(index_n + n - m) * stride] = Nnm / SAF_SQRT4PI * leg_n[m] * sinf((float)m * a);
+                        Y[(long long)(index_n + n + m) * stride] = Nnm / SAF_SQRT4PI * leg_n[m] * cosf((float)m * a);
                     }
                 }
             }
@@ -157,6 +155,33 @@ __global__ void sh_recur_kernel(int N, const float* dirs, int nDirs, float* Y, i
         }
         for (int i = 0; i <= N; i++) { leg_n_2[i] = leg_n_1[i]; leg_n_1[i] = leg_n[i]; }
     }
+}
+
+__global__ void sh_recur_kernel(int N, const float* dirs, int nDirs, float* Y, int mode)
+{
+    const int dir = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dir >= nDirs) return;
+    sh_recur_one(N, dirs[dir * 2 + 0], dirs[dir * 2 + 1], mode, Y + dir, nDirs);
+}
+
+/* ambi_enc_process, "recalculate SHs" (ambi_enc.c:120-131): for every flagged source of every instance
+ * Y[inst][:, ch] = getRSH_recur(order, dir), rows beyond nSH zeroed.  Y[inst] is [64][64] at instance stride y_inst, row stride 64
+ * (= MAX_NUM_INPUTS).  grid = nInst, block = 64 (one thread per source). */
+__global__ void enc_update_Y_kernel(const int* order, const float* dirs, const int* recalc, float* Y, long long y_inst)
+{
+    const int inst = blockIdx.x, ch = threadIdx.x;
+    if (!recalc[inst * SAF_MAXCH + ch]) return;
+    const int N = order[inst];
+    float* y = Y + (long long)inst * y_inst + ch;
+    sh_recur_one(N, dirs[(inst * SAF_MAXCH + ch) * 2 + 0], dirs[(inst * SAF_MAXCH + ch) * 2 + 1], 1, y, SAF_MAXCH);
+    for (int j = ORDER2NSH(N); j < SAF_MAXCH; j++) y[j * SAF_MAXCH] = 0.0f;
+}
+
+void launch_enc_update_Y(const int* d_order, const float* d_dirs, const int* d_recalc, float* d_Y, long long y_inst, int nInst)
+{
+    ensure_factorials();
+    hipLaunchKernelGGL(enc_update_Y_kernel, dim3(nInst), dim3(SAF_MAXCH), 0, stream(), d_order, d_dirs, d_recalc, d_Y, y_inst);
+    HIP_CHECK(hipGetLastError());
 }
 
 /* kind: 0 getSHreal, 1 getRSH, 2 getSHreal_recur, 3 getRSH_recur; device pointers */

@@ -56,7 +56,27 @@ def generate(O):
     mc = O.MatrixConv(64, H, 1)
     xc = frames(303, 3, 5 * 64)
     out["matrixconv_small"] = {"out": np.concatenate([mc.apply(xc[:, i * 64:(i + 1) * 64]) for i in range(5)], 1)}
+    out["ambi_enc_small"] = {"out": ambi_enc_scenario(O.AmbiEnc)}
     return out
+
+
+def ambi_enc_scenario(cls, F=256, nFrames=8):
+    """SURVEY Appendix D scenario: order 3, 3 sources, one gain 0.5, SN3D, post-scaling, a direction change before frame 3
+    and a gain change before frame 5."""
+    e = cls(F); e.init(48000)
+    e.setOutputOrder(3); e.setNumSources(3)
+    for i, (az, el) in enumerate([(30.0, 10.0), (-110.0, 45.0), (170.0, -30.0)]):
+        e.setSourceAzi_deg(i, az); e.setSourceElev_deg(i, el)
+    e.setSourceGain(1, 0.5)
+    x = frames(404, 3, nFrames * F)
+    ys = []
+    for f in range(nFrames):
+        if f == 3:
+            e.setSourceAzi_deg(0, -75.0); e.setSourceElev_deg(2, 60.0)
+        if f == 5:
+            e.setSourceGain(2, 1.5)
+        ys.append(e.process(x[:, f * F:(f + 1) * F], 18))
+    return np.concatenate(ys, 1)
 
 
 if __name__ == "__main__":
