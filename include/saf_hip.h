@@ -275,6 +275,21 @@ SAF_API void  saf_hip_ambi_enc_batch_process(void* const hBatch,
                                              float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride, int nOutputs,
                                              int nFrames);
 
+/* ========================================================================== */
+/*      matrix convolver (saf_utility_matrixConv.h:55-86)                     */
+/* ========================================================================== */
+/** H is nCHout x nCHin x length_h (host, copied); inputSig nCHin x hopSize, outputSig nCHout x hopSize (host, flat). */
+SAF_API void saf_matrixConv_create(void** const phMC, int hopSize, float* H, int length_h, int nCHin, int nCHout, int usePartFLAG); /* saf_utility_matrixConv.h:55 */
+SAF_API void saf_matrixConv_destroy(void** const phMC);                                                                           /* saf_utility_matrixConv.h:68 */
+SAF_API void saf_matrixConv_apply(void* const hMC, float* inputSig, float* outputSig);                                             /* saf_utility_matrixConv.h:81 */
+/** Device-pointer entry point: nBlocks consecutive blocks per call,
+ *  in[blk*in_block_stride + ch*in_ch_stride + n], out likewise (floats).  State carries over between calls exactly as
+ *  between consecutive saf_matrixConv_apply calls.  Handles are created for at most the number of blocks per call set by
+ *  saf_hip_matrixConv_setMaxBlocksPerCall (process-wide, read by saf_matrixConv_create; default 1). */
+SAF_API void saf_hip_matrixConv_setMaxBlocksPerCall(int nBlocks);
+SAF_API void saf_hip_matrixConv_apply_dev(void* const hMC, const float* d_in, long long in_ch_stride, long long in_block_stride,
+                                          float* d_out, long long out_ch_stride, long long out_block_stride, int nBlocks);
+
 #ifdef __cplusplus
 }
 #endif

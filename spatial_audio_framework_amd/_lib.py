@@ -143,5 +143,11 @@ def load():
     sig("saf_hip_ambi_enc_batch_create", vp, C.POINTER(vp), ci, ci)
     sig("saf_hip_ambi_enc_batch_destroy", None, C.POINTER(vp))
     sig("saf_hip_ambi_enc_batch_process", None, vp, vp, cll, cll, cll, ci, vp, cll, cll, cll, ci, ci)
+    # matrix convolver
+    sig("saf_matrixConv_create", None, C.POINTER(vp), ci, fp, ci, ci, ci, ci)
+    sig("saf_matrixConv_destroy", None, C.POINTER(vp))
+    sig("saf_matrixConv_apply", None, vp, fp, fp)
+    sig("saf_hip_matrixConv_setMaxBlocksPerCall", None, ci)
+    sig("saf_hip_matrixConv_apply_dev", None, vp, vp, cll, cll, vp, cll, cll, ci)
     _lib = L
     return L

@@ -307,3 +307,32 @@ class AmbiEncBatch:
     def __del__(self):
         if getattr(self, "hb", None):
             self.L.saf_hip_ambi_enc_batch_destroy(C.byref(self.hb))
+
+
+# ---------------------------------------------------------------- matrix convolver
+class MatrixConv:
+    """saf_matrixConv_* (saf_utility_matrixConv.h:55-86); H [nOut][nIn][len]."""
+
+    def __init__(self, hop, H, part=1, maxBlocks=1):
+        H = np.ascontiguousarray(H, np.float32)
+        self.nOut, self.nIn, self.len = H.shape
+        self.hop = hop
+        self.L = load()
+        self.h = vp()
+        self.L.saf_hip_matrixConv_setMaxBlocksPerCall(maxBlocks)
+        self.L.saf_matrixConv_create(C.byref(self.h), hop, _f(H), self.len, self.nIn, self.nOut, part)
+        self.L.saf_hip_matrixConv_setMaxBlocksPerCall(1)
+
+    def apply(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((self.nOut, self.hop), np.float32)
+        self.L.saf_matrixConv_apply(self.h, _f(x), _f(y))
+        return y
+
+    def apply_dev(self, d_in, in_strides, d_out, out_strides, nBlocks):
+        """strides = (ch, block) in floats."""
+        self.L.saf_hip_matrixConv_apply_dev(self.h, vp(d_in), *in_strides, vp(d_out), *out_strides, nBlocks)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.saf_matrixConv_destroy(C.byref(self.h))

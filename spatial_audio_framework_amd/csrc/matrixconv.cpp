@@ -1,0 +1,135 @@
+/*
+ * matrixconv.cpp — saf_matrixConv_create / _apply / _destroy
+ * (framework/modules/saf_utilities/saf_utility_matrixConv.h:55-86, .c:37-236) on the GPU.
+ *
+ * Both reference modes are linear convolution with zero latency
+ *     y_o[n] = sum_i sum_k H[o][i][k] x_i[n-k]
+ * computed block-wise in the frequency domain.  Partitioned mode splits the filters into
+ * nFB = ceil(len/hop) partitions and keeps a delay line of input spectra; non-partitioned mode
+ * is the same machinery with one partition and a longer transform.  State per handle (device):
+ * ring of input spectra, ring of the last inverse transforms (the overlap-add buffer).
+ */
+#include "saf_hip_common.h"
+#include "../../include/saf_hip.h"
+
+namespace saf {
+
+struct MatrixConv {
+    int hop, len, nIn, nOut, part;
+    int nFB, N, nBinsP, nOB, kSplit, termsPerSplit, maxBlocks;
+    int xRing, zRing;
+    long long blk = 0;              /* absolute index of the next block */
+    DevBuf<float2> tw, Hf, Xr, P;
+    DevBuf<float> zs, d_in, d_out;
+    PinBuf<float> h_in, h_out;
+
+    void size_scratch(int T)
+    {
+        if (T <= maxBlocks) return;
+        /* growing the rings would lose their phase: rings are sized once for maxBlocks at creation */
+        SAF_FATAL("matrixConv: %d blocks per call exceed the %d the handle was created for", T, maxBlocks);
+    }
+
+    void create(int hopSize, const float* H, int length_h, int nCHin, int nCHout, int usePart, int maxBlocks_)
+    {
+        hop = hopSize; len = length_h; nIn = nCHin; nOut = nCHout; part = usePart ? 1 : 0; maxBlocks = maxBlocks_;
+        if (hop < 1 || len < 1 || nIn < 1 || nOut < 1) SAF_FATAL("matrixConv: bad dimensions");
+        int partLen;
+        if (part) { nFB = (len + hop - 1) / hop; partLen = hop; }                  /* saf_utility_matrixConv.c:107 */
+        else      { nFB = 1; partLen = len; }
+        const int Lz = hop + partLen - 1;                                            /* length of one block's linear convolution */
+        nOB = (Lz + hop - 1) / hop;                                                  /* = numOvrlpAddBlocks (:71) / 2 in partitioned mode */
+        N = 4; while (N < Lz || N < 2 * hop) N <<= 1;
+        if (N > 32768) SAF_FATAL("matrixConv: transform size %d exceeds the supported 32768 (use the partitioned mode)", N);
+        nBinsP = N / 2 + 4;                                                          /* rows padded to a 16-byte multiple */
+        xRing = nFB - 1 + maxBlocks; zRing = nOB - 1 + maxBlocks;
+        const int nTerms = nFB * nIn;
+        /* enough workgroups to pull the filter spectra at HBM rate: split the (partition, input) sum */
+        const int tiles = ((N / 2 + 1 + 63) / 64) * nOut;
+        kSplit = (1024 + tiles - 1) / tiles; if (kSplit > (nTerms + 3) / 4) kSplit = (nTerms + 3) / 4; if (kSplit < 1) kSplit = 1;
+        termsPerSplit = (nTerms + kSplit - 1) / kSplit;
+        kSplit = (nTerms + termsPerSplit - 1) / termsPerSplit;
+        pconv_twiddles(N, tw);
+        Hf.alloc((size_t)nOut * nTerms * nBinsP);
+        Xr.alloc((size_t)xRing * nIn * nBinsP);
+        P.alloc((size_t)maxBlocks * nOut * kSplit * nBinsP);
+        zs.alloc((size_t)zRing * nOut * N);
+        /* filter spectra: partition p of H[o][i] = taps [p*partLen, (p+1)*partLen) zero-padded to N (:116-125) */
+        DevBuf<float> dH; dH.alloc((size_t)nOut * nIn * len, false);
+        HIP_CHECK(hipMemcpyAsync(dH.p, H, sizeof(float) * (size_t)nOut * nIn * len, hipMemcpyHostToDevice, stream()));
+        PconvFwd f{};
+        f.src = dH.p; f.s0 = len; f.s1 = partLen; f.s2 = (long long)nIn * len;
+        f.nValid = partLen; f.yValidStep = partLen; f.yValidTotal = len;
+        f.dst = Hf.p; f.d0 = nBinsP; f.d1 = (long long)nIn * nBinsP; f.d2 = (long long)nTerms * nBinsP;
+        f.ringLen = 0; f.ringHead = 0; f.tw = tw.p; f.N = N; f.g0 = nIn; f.g1 = nFB; f.g2 = nOut;
+        pconv_launch_fwd(f);
+        HIP_CHECK(hipStreamSynchronize(stream()));      /* dH is released on return */
+    }
+
+    void apply_dev(const float* in, long long in_ch, long long in_blk, float* out, long long out_ch, long long out_blk, int T)
+    {
+        if (T <= 0) return;
+        size_scratch(T);
+        const int xHead = (int)(blk % xRing), zHead = (int)(blk % zRing);
+        PconvFwd f{};
+        f.src = in; f.s0 = in_ch; f.s1 = in_blk; f.s2 = 0; f.nValid = hop; f.yValidStep = 0; f.yValidTotal = 0;
+        f.dst = Xr.p; f.d0 = nBinsP; f.d1 = (long long)nIn * nBinsP; f.d2 = 0; f.ringLen = xRing; f.ringHead = xHead;
+        f.tw = tw.p; f.N = N; f.g0 = nIn; f.g1 = T; f.g2 = 1;
+        pconv_launch_fwd(f);
+        PconvApply a{};
+        a.Hf = Hf.p; a.Xr = Xr.p; a.P = P.p; a.zs = zs.p; a.out = out; a.out_ch = out_ch; a.out_blk = out_blk; a.tw = tw.p;
+        a.nIn = nIn; a.nOut = nOut; a.nFB = nFB; a.N = N; a.hop = hop; a.nOB = nOB; a.nBinsP = nBinsP; a.kSplit = kSplit; a.termsPerSplit = termsPerSplit;
+        a.xRing = xRing; a.xHead = xHead; a.zRing = zRing; a.zHead = zHead; a.T = T;
+        pconv_launch_apply(a);
+        blk += T;
+    }
+};
+
+}  // namespace saf
+
+using namespace saf;
+
+static int g_matrixconv_max_blocks = 1;
+
+extern "C" {
+
+void saf_hip_matrixConv_setMaxBlocksPerCall(int n) { g_matrixconv_max_blocks = n < 1 ? 1 : n; }
+
+void saf_matrixConv_create(void** const phMC, int hopSize, float* H, int length_h, int nCHin, int nCHout, int usePartFLAG)
+{
+    ensure_device();
+    MatrixConv* h = new MatrixConv();
+    h->create(hopSize, H, length_h, nCHin, nCHout, usePartFLAG, g_matrixconv_max_blocks);
+    *phMC = h;
+}
+
+void saf_matrixConv_destroy(void** const phMC)
+{
+    MatrixConv* h = (MatrixConv*)*phMC;
+    if (!h) return;
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    delete h;
+    *phMC = nullptr;
+}
+
+void saf_matrixConv_apply(void* const hMC, float* inputSig, float* outputSig)
+{
+    MatrixConv* h = (MatrixConv*)hMC;
+    const size_t nin = (size_t)h->nIn * h->hop, nout = (size_t)h->nOut * h->hop;
+    h->h_in.ensure(nin); h->h_out.ensure(nout);
+    if (!h->d_in.p) { h->d_in.alloc(nin, false); h->d_out.alloc(nout, false); }
+    memcpy(h->h_in.p, inputSig, sizeof(float) * nin);
+    HIP_CHECK(hipMemcpyAsync(h->d_in.p, h->h_in.p, sizeof(float) * nin, hipMemcpyHostToDevice, stream()));
+    h->apply_dev(h->d_in.p, h->hop, 0, h->d_out.p, h->hop, 0, 1);
+    HIP_CHECK(hipMemcpyAsync(h->h_out.p, h->d_out.p, sizeof(float) * nout, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    memcpy(outputSig, h->h_out.p, sizeof(float) * nout);
+}
+
+void saf_hip_matrixConv_apply_dev(void* const hMC, const float* d_in, long long in_ch_stride, long long in_block_stride,
+                                  float* d_out, long long out_ch_stride, long long out_block_stride, int nBlocks)
+{
+    ((MatrixConv*)hMC)->apply_dev(d_in, in_ch_stride, in_block_stride, d_out, out_ch_stride, out_block_stride, nBlocks);
+}
+
+}

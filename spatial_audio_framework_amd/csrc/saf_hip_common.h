@@ -166,4 +166,19 @@ struct EncLaunch {
 };
 void launch_enc_gemm(const EncLaunch& e);
 
+/* ---- FFT-domain matrix convolution (pconv_kernels.hip) ---- */
+struct PconvFwd {           /* zero-padded real FFT of size N for every (x, y, z) of the grid */
+    const float* src; long long s0, s1, s2; int nValid, yValidStep, yValidTotal;
+    float2* dst; long long d0, d1, d2; int ringLen, ringHead;
+    const float2* tw; int N; int g0, g1, g2;
+};
+void pconv_launch_fwd(const PconvFwd& f);
+struct PconvApply {         /* MAC over (partition, input) + one inverse FFT per output + overlap-add, for T blocks */
+    const float2* Hf; const float2* Xr; float2* P; float* zs; float* out; long long out_ch, out_blk;
+    const float2* tw;
+    int nIn, nOut, nFB, N, hop, nOB, nBinsP, kSplit, termsPerSplit, xRing, xHead, zRing, zHead, T;
+};
+void pconv_launch_apply(const PconvApply& p);
+void pconv_twiddles(int N, DevBuf<float2>& tw);
+
 }  // namespace saf
