@@ -14,76 +14,116 @@
  * 6 more for the hybrid half-band FIR and its 3-hop delay) and (b) the last 9
  * synthesised frames for the 10-segment overlap-add.
  *
- * Mapping: one workgroup (4 waves) per (instance, channel[, hop chunk]); one
- * 64-lane wave per hop computes the 256-point real FFT as a 128-point complex
- * FFT with two points per lane: six radix-2 stages exchange across lanes
- * (wave shuffles, no LDS traffic), the seventh is in-lane.  Spectra of a
- * 16-hop sub-chunk are staged in LDS so that every global store/load of the
- * [band][channel][time] layout is a full 128-byte line.
+ * Mapping: one workgroup (4 waves) per (instance, channel PAIR[, hop chunk]), working through the
+ * hops in sub-chunks of 16.  Per sub-chunk three phases share one LDS ring of 1 KiB spectrum slots:
+ *   analysis : window fold (thread = sample position, sliding 10-hop register window, input read once
+ *              from HBM)  ->  32 FFTs  ->  hybrid split + time-contiguous store of [band][ch][hop]
+ *   synthesis: time-contiguous gather + hybrid merge  ->  32 inverse FFTs  ->  10-segment overlap-add
+ *              (thread = sample position, frame history in registers)
+ * The 256-point real FFT is a 128-point complex FFT done by 8 lanes x 16 points: a radix-4x4 DFT-16
+ * in registers, the W128 twiddles, an 8x16 transpose through the FFT's own LDS slot (XOR-swizzled,
+ * conflict-free), two DFT-8 in registers.  No cross-lane shuffles, ~45 wave-instructions per FFT.
  */
 #include "saf_hip_common.h"
 
 namespace saf {
 
-#define SUB      16      /* hops per sub-chunk */
-#define SPEC_LD  129     /* odd leading dimension: conflict-free across slots */
-#define RING     22      /* SUB + 6 spectra kept for the hybrid filter */
-#define G_LD     288     /* 256 + 32: padded so the bit-reversed float4 stores spread over the banks */
+#define SUB       16      /* hops per sub-chunk */
+#define ARING     22      /* analysis ring: SUB + 6 spectra kept for the hybrid filter */
+#define OLA       8       /* hops per overlap-add register window */
+#define SLOT      272     /* floats per LDS slot: 256 + 16, slot stride = 16 banks -> the 4 FFTs of a lane group never collide */
 
 #define COEFF1 0.031273141818515176604f   /* afSTFT_internal.h:74 */
 #define COEFF2 0.28127313041521179171f    /* afSTFT_internal.h:75 */
+#define RSQRT2 0.70710678118654752440f
 
-__device__ __forceinline__ int bitrev6(int x) { return (int)(__brev((unsigned)x) >> 26); }
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every barrier would then wait
+ * for the prefetched input loads and for the spectra / sample stores still on their way to HBM. */
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { /* a * conj(b) */ return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
-__device__ __forceinline__ float2 shflx(float2 v, int h) { return make_float2(__shfl_xor(v.x, h), __shfl_xor(v.y, h)); }
-__device__ __forceinline__ float2 shfl(float2 v, int src) { return make_float2(__shfl(v.x, src), __shfl(v.y, src)); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+/* multiply by -i (forward) or +i (inverse) */
+template <bool INV> __device__ __forceinline__ float2 rot90(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+/* multiply by a constant twiddle given for the FORWARD transform (conjugated for the inverse) */
+template <bool INV> __device__ __forceinline__ float2 twc(float2 a, float wr, float wi) { return cmul(a, make_float2(wr, INV ? -wi : wi)); }
 
-/* per-lane twiddles: rows 0..5 = W_{2h}^{lane & (h-1)}, h = 1<<row; row 6 = W_128^lane; row 7 = W_256^lane (forward sign) */
-struct LaneTw { float2 st[6]; float2 w128; float2 w256; };
-__device__ __forceinline__ LaneTw load_tw(const float2* tw, int lane)
+template <bool INV> __device__ __forceinline__ void dft4(float2& x0, float2& x1, float2& x2, float2& x3)
 {
-    LaneTw t;
-#pragma unroll
-    for (int s = 0; s < 6; s++) t.st[s] = tw[s * 64 + lane];
-    t.w128 = tw[6 * 64 + lane];
-    t.w256 = tw[7 * 64 + lane];
-    return t;
+    const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2), t2 = cadd(x1, x3), t3 = rot90<INV>(csub(x1, x3));
+    x0 = cadd(t0, t2); x1 = cadd(t1, t3); x2 = csub(t0, t2); x3 = csub(t1, t3);
 }
 
-/* 128-point complex forward FFT, decimation in time.  In: lane holds z[2q], z[2q+1], q = bitrev6(lane).
- * Out: A = Z[lane], B = Z[lane + 64]. */
-__device__ __forceinline__ void fft128_fwd(float2 e, float2 o, const LaneTw& tw, int lane, float2& A, float2& B)
+/* 16-point DFT in registers, radix 4 x 4.  In: v[m].  Out: X[p] is left in v[4*(p&3) + (p>>2)]. */
+template <bool INV> __device__ __forceinline__ void dft16(float2 (&v)[16])
 {
 #pragma unroll
-    for (int s = 0; s < 6; s++) {
-        const int h = 1 << s;
-        const bool up = (lane & h) != 0;
-        float2 te = up ? cmul(e, tw.st[s]) : e;
-        float2 to = up ? cmul(o, tw.st[s]) : o;
-        float2 pe = shflx(te, h), po = shflx(to, h);
-        e = up ? make_float2(pe.x - te.x, pe.y - te.y) : make_float2(te.x + pe.x, te.y + pe.y);
-        o = up ? make_float2(po.x - to.x, po.y - to.y) : make_float2(to.x + po.x, to.y + po.y);
+    for (int b = 0; b < 4; b++) dft4<INV>(v[b], v[4 + b], v[8 + b], v[12 + b]);     /* v[4c+b] = y_b[c] */
+    /* y_b[c] *= W16^(b*c) */
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;       /* cos, sin(pi/8) */
+    v[4 * 1 + 1] = twc<INV>(v[4 * 1 + 1], c1, -s1);                                 /* W16^1 */
+    v[4 * 1 + 2] = twc<INV>(v[4 * 1 + 2], RSQRT2, -RSQRT2);                         /* W16^2 */
+    v[4 * 1 + 3] = twc<INV>(v[4 * 1 + 3], s1, -c1);                                 /* W16^3 */
+    v[4 * 2 + 1] = twc<INV>(v[4 * 2 + 1], RSQRT2, -RSQRT2);                         /* W16^2 */
+    v[4 * 2 + 2] = rot90<INV>(v[4 * 2 + 2]);                                        /* W16^4 = -i */
+    v[4 * 2 + 3] = twc<INV>(v[4 * 2 + 3], -RSQRT2, -RSQRT2);                        /* W16^6 */
+    v[4 * 3 + 1] = twc<INV>(v[4 * 3 + 1], s1, -c1);                                 /* W16^3 */
+    v[4 * 3 + 2] = twc<INV>(v[4 * 3 + 2], -RSQRT2, -RSQRT2);                        /* W16^6 */
+    v[4 * 3 + 3] = twc<INV>(v[4 * 3 + 3], -c1, s1);                                 /* W16^9 */
+#pragma unroll
+    for (int c = 0; c < 4; c++) dft4<INV>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);   /* v[4c+d] = X[c+4d] */
+}
+#define X16(v, p) v[4 * ((p) & 3) + ((p) >> 2)]
+
+/* 8-point DFT in registers.  In: v[j].  Out: X[q] is left in v[2*(q&3) + (q>>2)]. */
+template <bool INV> __device__ __forceinline__ void dft8(float2 (&v)[8])
+{
+    dft4<INV>(v[0], v[2], v[4], v[6]);          /* v[2c]   = y_0[c] */
+    dft4<INV>(v[1], v[3], v[5], v[7]);          /* v[2c+1] = y_1[c] */
+    v[3] = twc<INV>(v[3], RSQRT2, -RSQRT2);     /* W8^1 */
+    v[5] = rot90<INV>(v[5]);                    /* W8^2 */
+    v[7] = twc<INV>(v[7], -RSQRT2, -RSQRT2);    /* W8^3 */
+#pragma unroll
+    for (int c = 0; c < 4; c++) { const float2 u = v[2 * c], w = v[2 * c + 1]; v[2 * c] = cadd(u, w); v[2 * c + 1] = csub(u, w); }
+}
+#define X8(v, q) v[2 * ((q) & 3) + ((q) >> 2)]
+
+/* 128-point complex FFT of the sequence stored in one LDS slot (z[n] at floats 2n, 2n+1), in place, by the
+ * 8 lanes j = 0..7 of one FFT group (all in one wave: LDS operations of a wave execute in order, so the
+ * group needs no barrier).  twJ[p] = exp(-2 pi i j p / 128).  Result Z[k] at floats 2k, 2k+1. */
+template <bool INV, typename TW> __device__ __forceinline__ void fft128_slot(float* slot, int j, const TW& twJ)
+{
+    float2 v[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m] = *reinterpret_cast<const float2*>(slot + 2 * j + 16 * m);      /* z[j + 8m] */
+    dft16<INV>(v);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    /* transpose buffer T[p][j] at floats 16p + 2*(j ^ (p&7)) */
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        float2 w = twJ[p]; if (INV) w.y = -w.y;
+        const float2 c = p == 0 ? X16(v, 0) : cmul(X16(v, p), w);
+        *reinterpret_cast<float2*>(slot + 16 * p + 2 * (j ^ (p & 7))) = c;
     }
-    float2 t = cmul(o, tw.w128);
-    A = make_float2(e.x + t.x, e.y + t.y);
-    B = make_float2(e.x - t.x, e.y - t.y);
-}
-
-/* 128-point complex inverse FFT (unscaled), decimation in frequency.  In: a = Z[lane], b = Z[lane+64].
- * Out: lane holds z[2q] (a), z[2q+1] (b), q = bitrev6(lane). */
-__device__ __forceinline__ void fft128_inv(float2& a, float2& b, const LaneTw& tw, int lane)
-{
-    float2 s = make_float2(a.x + b.x, a.y + b.y);
-    float2 d = cmulc(make_float2(a.x - b.x, a.y - b.y), tw.w128);
-    a = s; b = d;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float2 a[8], b[8];
 #pragma unroll
-    for (int st = 5; st >= 0; st--) {
-        const int h = 1 << st;
-        const bool up = (lane & h) != 0;
-        float2 pa = shflx(a, h), pb = shflx(b, h);
-        a = up ? cmulc(make_float2(pa.x - a.x, pa.y - a.y), tw.st[st]) : make_float2(a.x + pa.x, a.y + pa.y);
-        b = up ? cmulc(make_float2(pb.x - b.x, pb.y - b.y), tw.st[st]) : make_float2(b.x + pb.x, b.y + pb.y);
+    for (int i = 0; i < 8; i++) {
+        a[i] = *reinterpret_cast<const float2*>(slot + 16 * j + 2 * (i ^ j));
+        b[i] = *reinterpret_cast<const float2*>(slot + 16 * (j + 8) + 2 * (i ^ j));
+    }
+    dft8<INV>(a); dft8<INV>(b);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        *reinterpret_cast<float2*>(slot + 2 * (j + 16 * q)) = X8(a, q);          /* Z[j + 16q] */
+        *reinterpret_cast<float2*>(slot + 2 * (j + 8 + 16 * q)) = X8(b, q);      /* Z[j + 8 + 16q] */
     }
 }
 
@@ -93,141 +133,221 @@ __device__ __forceinline__ void fft128_inv(float2& a, float2& b, const LaneTw& t
 
 struct AnaArgs {
     AnaLaunch a;
-    const float* win;
-    const float2* tw;
+    const float* win;      /* [1280] */
+    const float2* twJ;     /* [8][16]  exp(-2 pi i j p / 128) */
+    const float2* tw256;   /* [129]    exp(-2 pi i k / 256) */
     int chunk;
+    int dbg;               /* timing experiments only (SAF_DBG): bit0 no fold, bit1 no FFT, bit2 no store phase, bit3 no global stores, bit4 no prefetch */
 };
 
-__device__ __forceinline__ float4 ana_load4(const AnaArgs& g, int inst, int ch, int srcch, bool valid, float scale, int hop, int c4)
+/* bins k and 128-k (k = 0..64) of the 256-point real FFT from the packed 128-point spectrum in an LDS slot
+ * (kiss_fftr.c:86-123 convention).  k = 0 gives X[0] and X[128] (Z[128] := Z[0], W256^0 = 1). */
+__device__ __forceinline__ void ana_bin_pair(const float* slot, int k, float2 W, float2& Xk, float2& Xm)
 {
-    if (hop < 0) {
-        const float* p = g.a.hist_rd + (((long long)inst * g.a.nCh + ch) * SAF_ANA_HIST + (SAF_ANA_HIST + hop)) * SAF_HOP + c4 * 4;
-        return *reinterpret_cast<const float4*>(p);
-    }
-    if (!valid) return make_float4(0.f, 0.f, 0.f, 0.f);
-    const int frame = hop / g.a.hopsPerFrame, sub = hop - frame * g.a.hopsPerFrame;
-    const float* p = g.a.in + (long long)inst * g.a.in_inst + (long long)frame * g.a.in_frame + (long long)srcch * g.a.in_ch + sub * SAF_HOP + c4 * 4;
-    float4 v = *reinterpret_cast<const float4*>(p);
-    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-    return v;
+    const float2 Zk = *reinterpret_cast<const float2*>(slot + 2 * k);
+    const float2 Zm = *reinterpret_cast<const float2*>(slot + 2 * ((128 - k) & 127));
+    const float2 e = make_float2(Zk.x + Zm.x, Zk.y - Zm.y);
+    const float2 d = make_float2(Zk.x - Zm.x, Zk.y + Zm.y);
+    const float2 t = cmul(W, d);
+    Xk = make_float2(0.5f * (e.x + t.y), 0.5f * (e.y - t.x));
+    Xm = make_float2(0.5f * (e.x - t.y), 0.5f * (-e.y - t.x));
+}
+__device__ __forceinline__ float2 ana_bin_lo(const float* slot, int k, float2 W)
+{
+    float2 a, b;
+    ana_bin_pair(slot, k, W, a, b);
+    return a;
 }
 
-__global__ __launch_bounds__(256) void afstft_analysis_kernel(AnaArgs g)
+__global__ __launch_bounds__(256, 3) void afstft_analysis_kernel(AnaArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float s_in[(SUB + 9) * SAF_HOP];
-    __shared__ float s_re[RING * SPEC_LD];
-    __shared__ float s_im[RING * SPEC_LD];
+    __shared__ __attribute__((aligned(16))) float s_ring[2 * ARING * SLOT];
+    __shared__ float2 s_tw256[130];
+    __shared__ float2 s_twJ[8 * 16];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.y, inst = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int inst = blockIdx.z;
+    const int chBase = blockIdx.y * 2;
     const int c0 = blockIdx.x * g.chunk;
     const int c1 = min(c0 + g.chunk, g.a.H);
     if (c0 >= c1) return;
-
     const int tabStride = g.a.tab_stride ? g.a.tab_stride : g.a.nCh;
-    const int srcch = g.a.ch_map ? g.a.ch_map[inst * tabStride + ch] : ch;
-    const bool valid = srcch >= 0 && srcch < g.a.nChIn;
-    const float scale = g.a.ch_scale ? g.a.ch_scale[inst * tabStride + ch] : 1.0f;
-    const int nBandsOut = g.a.hybrid ? SAF_NBANDS : SAF_NBINS;
+    const int T = g.a.hopsPerFrame;
 
-    /* per-lane constants: which 4 folded samples this lane produces, and their 5 window taps each */
-    const int q = bitrev6(lane);
-    const int odd = q >> 5;                 /* 0: first half of the 256-frame (even k), 1: second half (odd k) */
-    const int n0 = 4 * (q & 31);
-    float4 w[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) w[i] = *reinterpret_cast<const float4*>(g.win + (2 * i + odd) * SAF_HOP + n0);
-    const LaneTw tw = load_tw(g.tw, lane);
+    for (int k = tid; k < 129; k += 256) s_tw256[k] = g.tw256[k];
+    if (tid < 128) s_twJ[tid] = g.twJ[tid];
 
-    for (int s0 = c0 - 6; s0 < c1;) {
-        const int n = (s0 < c0) ? 6 : min(SUB, c1 - s0);
-        /* stage input hops s0-9 .. s0+n-1 */
-        for (int idx = tid; idx < (n + 9) * 32; idx += 256) {
-            const int row = idx >> 5, c4 = idx & 31;
-            float4 v = ana_load4(g, inst, ch, srcch, valid, scale, s0 - 9 + row, c4);
-            *reinterpret_cast<float4*>(&s_in[row * SAF_HOP + c4 * 4]) = v;
-        }
-        __syncthreads();
-        for (int t = wave; t < n; t += 4) {
-            /* 1280-tap window + fold: f[(k&1)*128 + n] = sum_k x[hop-9+k][n] * w[k*128+n]   (afSTFT_internal.c:276-301) */
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    /* ---- fold role: thread = (channel of the pair, sample position) ---- */
+    const int fc = tid >> 7, fn = tid & 127;
+    const int fch = chBase + fc;
+    const bool fOn = fch < g.a.nCh;
+    const int fchc = fOn ? fch : g.a.nCh - 1;          /* the odd pair's missing channel shadows the last one (never stored) */
+    const int srcch = g.a.ch_map ? g.a.ch_map[inst * tabStride + fchc] : fchc;
+    const bool chValid = srcch >= 0 && srcch < g.a.nChIn;
+    const float scale = chValid ? (g.a.ch_scale ? g.a.ch_scale[inst * tabStride + fchc] : 1.0f) : 0.0f;
+    /* every load is  uniform 64-bit base  +  32-bit per-thread offset, unconditional (a load under a branch gets its own
+     * wait and would serialise a sub-chunk's 16 loads into 16 HBM round trips) */
+    const unsigned offIn = (unsigned)((chValid ? srcch : 0) * g.a.in_ch + fn);
+    const unsigned offHist = (unsigned)(fchc * (SAF_ANA_HIST * SAF_HOP) + fn);
+    const float* inBase = g.a.in + (long long)inst * g.a.in_inst;
+    const float* histBase = g.a.hist_rd + (long long)inst * g.a.nCh * (SAF_ANA_HIST * SAF_HOP);
+    float w[10];
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
-                const int k = 2 * i + odd;
-                const float4 x = *reinterpret_cast<const float4*>(&s_in[(t + k) * SAF_HOP + n0]);
-                acc.x = fmaf(x.x, w[i].x, acc.x); acc.y = fmaf(x.y, w[i].y, acc.y);
-                acc.z = fmaf(x.z, w[i].z, acc.z); acc.w = fmaf(x.w, w[i].w, acc.w);
-            }
-            float2 A, B;
-            fft128_fwd(make_float2(acc.x, acc.y), make_float2(acc.z, acc.w), tw, lane, A, B);
-            /* real-FFT split: X[k], X[128-k] from Z[k], Z[128-k]  (kiss_fftr.c:86-123 convention) */
-            const float2 Zmk = shfl(B, (64 - lane) & 63);
-            const float2 f1 = make_float2(A.x + Zmk.x, A.y - Zmk.y);
-            const float2 f2 = make_float2(A.x - Zmk.x, A.y + Zmk.y);
-            const float2 tt = cmul(f2, tw.w256);
-            float2 Xk = make_float2(0.5f * (f1.x + tt.y), 0.5f * (f1.y - tt.x));
-            float2 Xmk = make_float2(0.5f * (f1.x - tt.y), 0.5f * (-f1.y - tt.x));
-            const int slot = (s0 + t - c0 + 6) % RING;
-            float* re = &s_re[slot * SPEC_LD];
-            float* im = &s_im[slot * SPEC_LD];
-            if (lane == 0) {
-                re[0] = A.x + A.y;   im[0] = 0.f;          /* DC */
-                re[128] = A.x - A.y; im[128] = 0.f;        /* Nyquist */
-                re[64] = B.x;        im[64] = -B.y;        /* bin 64 = conj(Z[64]) */
-            } else {
-                re[lane] = Xk.x;        im[lane] = Xk.y;
-                re[128 - lane] = Xmk.x; im[128 - lane] = Xmk.y;
+    for (int k = 0; k < 10; k++) w[k] = g.win[k * SAF_HOP + fn];
+
+    /* ---- FFT role: thread = (FFT of the sub-chunk, lane j of its group of 8) ---- */
+    const int ff = tid >> 3, fj = tid & 7;
+    const int fftC = ff >> 4, fftT = ff & 15;
+    const float2* twJ = s_twJ + fj * 16;
+
+    /* input cursor: element offset of the next non-negative hop inside this instance's input (uniform) */
+    int curHop = c0 - SAF_ANA_HIST < 0 ? 0 : c0 - SAF_ANA_HIST;
+    int curFrame = curHop / T, curSub = curHop - curFrame * T;
+    long long curOff = (long long)curFrame * g.a.in_frame + curSub * SAF_HOP;
+
+    /* window: xin[i] = x[hop h0 - 9 + i].  All loads a workgroup needs before its first FFT — the 9 hops before the
+     * warm-up, the 6 warm-up hops and the first sub-chunk — are issued back to back: one memory round trip. */
+    float xin[SUB + 9], xw[6];
+#pragma unroll
+    for (int i = 0; i < SAF_ANA_HIST; i++) {
+        const int h = c0 - SAF_ANA_HIST + i;                       /* uniform */
+        const float* base = h < 0 ? histBase + (SAF_ANA_HIST + h) * SAF_HOP : inBase + curOff;
+        const unsigned off = h < 0 ? offHist : offIn;
+        const float v = base[off] * (h < 0 ? 1.0f : scale);
+        if (i < 6) xw[i] = v; else xin[i - 6] = v;
+        if (h >= 0) { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += g.a.in_frame - (long long)T * SAF_HOP; } }
+    }
+#pragma unroll
+    for (int i = 0; i < SUB; i++) {
+        xin[9 + i] = (inBase + curOff)[offIn] * scale;
+        if (c0 + i + 1 < c1) { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += g.a.in_frame - (long long)T * SAF_HOP; } }
+    }
+    /* hop h of this chunk lives in ring position (h - (c0 - 6)) % ARING */
+    /* ---- prologue: spectra of the 6 warm-up hops c0-6 .. c0-1 (hybrid FIR history; nothing is stored).
+     *      Warm-up hop t folds x[c0-15+t .. c0-6+t] = xw[t..5], xin[0..t+3] ---- */
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        float fe = 0.0f, fo = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const int q = t + k;                                   /* index into the 15 hops c0-15 .. c0-1 */
+            const float xv = q < 6 ? xw[q < 6 ? q : 0] : xin[q >= 6 ? q - 6 : 0];
+            if (k & 1) fo = fmaf(xv, w[k], fo); else fe = fmaf(xv, w[k], fe);
+        }
+        float* slot = s_ring + (fc * ARING + t) * SLOT;
+        slot[fn] = fe; slot[128 + fn] = fo;
+    }
+    lds_barrier();
+    if (fftT < 6) fft128_slot<false>(s_ring + (fftC * ARING + fftT) * SLOT, fj, twJ);
+    /* (the barrier after the first fold below orders these spectra before their first use) */
+
+    float2* outBase = g.a.out + (long long)inst * g.a.out_inst + (long long)chBase * g.a.out_ch;
+    const unsigned ob32 = (unsigned)g.a.out_band, oc32 = (unsigned)g.a.out_ch;
+    const int st = tid & 15, sr = tid >> 4;                /* store role: hop of the sub-chunk, item lane */
+    const int nC = g.a.nCh - chBase >= 2 ? 2 : 1;
+
+    int p0 = 6;                                            /* ring position of the sub-chunk's first hop */
+    for (int s0 = c0; s0 < c1; s0 += SUB) {
+        const int n = min(SUB, c1 - s0);                   /* hops of this sub-chunk */
+        /* 1. window + fold (afSTFT_internal.c:276-301): f[(k&1)*128 + n] = sum_k x[hop-9+k][n] * w[k*128+n] */
+#pragma unroll
+        for (int t = 0; t < SUB; t++) {
+            if (t < n && !(g.dbg & 1)) {
+                float fe = 0.0f, fo = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
+                int pos = p0 + t; if (pos >= ARING) pos -= ARING;
+                float* slot = s_ring + (fc * ARING + pos) * SLOT;
+                slot[fn] = fe; slot[128 + fn] = fo;
             }
         }
-        __syncthreads();
-        if (s0 >= c0) {
-            /* hybrid split + 3-hop delay (afSTFT_internal.c:523-623), stored time-contiguous */
-            for (int idx = tid; idx < nBandsOut * SUB; idx += 256) {
-                const int band = idx >> 4, t = idx & 15;
-                if (t >= n) continue;
-                const int hop = s0 + t;
-                const int base = hop - c0 + 6;              /* ring position of S_hop */
-                const int sD = (base - 3) % RING;
-                float2 v;
+        /* the workgroup that owns the end of the launch records the new input history (the last 15 hops) from its window */
+        if (n == SUB && s0 + SUB == g.a.H && g.a.hist_wr && fOn) {
+            float* dst = g.a.hist_wr + ((long long)inst * g.a.nCh + fch) * SAF_ANA_HIST * SAF_HOP + fn;
+#pragma unroll
+            for (int row = 0; row < SAF_ANA_HIST; row++) dst[row * SAF_HOP] = xin[SUB + 9 - SAF_ANA_HIST + row];
+        }
+        /* slide the window and prefetch the next sub-chunk's input while the FFT and store phases run */
+#pragma unroll
+        for (int i = 0; i < 9; i++) xin[i] = xin[i + SUB];
+        if (s0 + SUB < c1 && !(g.dbg & 16)) {
+#pragma unroll
+            for (int i = 0; i < SUB; i++) {
+                xin[9 + i] = (inBase + curOff)[offIn] * scale;
+                if (s0 + SUB + i + 1 < c1) { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += g.a.in_frame - (long long)T * SAF_HOP; } }
+            }
+        }
+        lds_barrier();
+        /* 2. 256-point real FFT as a 128-point complex FFT of z[m] = f[2m] + i f[2m+1], in place in the slot */
+        if (fftT < n && !(g.dbg & 2)) {
+            int pos = p0 + fftT; if (pos >= ARING) pos -= ARING;
+            fft128_slot<false>(s_ring + (fftC * ARING + pos) * SLOT, fj, twJ);
+        }
+        lds_barrier();
+        /* 3. real-FFT split (bins k and 128-k share their inputs), hybrid split + 3-hop delay
+         *    (afSTFT_internal.c:523-623), stored time-contiguous: 16 lanes = 16 hops = one 128-byte row segment */
+        if (st < n && !(g.dbg & 4)) {
+            int pos = p0 + st; if (pos >= ARING) pos -= ARING;                 /* ring position of S_hop */
+            int pD = pos - 3; if (pD < 0) pD += ARING;                         /* all bands are delayed 3 hops */
+            if (!g.a.hybrid) pD = pos;                                         /* plain STFT bins, no hybrid delay */
+            const unsigned ohop = (unsigned)(s0 + st);
+            for (int ii = 0; ii < 9; ii++) {
+                const int item = sr + 16 * ii;
+                if (item >= 65 * nC) break;
+                const int c = item >= 65 ? 1 : 0;
+                const int k = item - 65 * c;
+                const float* ring = s_ring + c * ARING * SLOT;
+                const float2 W = s_tw256[k];
+                float2 Xk, Xm;
+                ana_bin_pair(ring + pD * SLOT, k, W, Xk, Xm);
+                const unsigned o = (unsigned)c * oc32 + ohop;
+                if (g.dbg & 8) { if (Xk.x == 123.456f) outBase[o] = Xm; continue; }
                 if (!g.a.hybrid) {
-                    const int p0 = base % RING;             /* plain STFT bins, no hybrid delay */
-                    v = make_float2(s_re[p0 * SPEC_LD + band], s_im[p0 * SPEC_LD + band]);
-                } else if (band == 0 || band >= 9) {
-                    const int bin = band == 0 ? 0 : band - 4;
-                    v = make_float2(s_re[sD * SPEC_LD + bin], s_im[sD * SPEC_LD + bin]);
+                    outBase[(unsigned)k * ob32 + o] = Xk;
+                    if (k != 64) outBase[(unsigned)(128 - k) * ob32 + o] = Xm;
                 } else {
-                    const int b = (band + 1) >> 1;
-                    const int p0 = base % RING, p2 = (base - 2) % RING, p4 = (base - 4) % RING, p6 = (base - 6) % RING;
-                    float gr, gi;
-                    gr = -COEFF1 * s_im[p0 * SPEC_LD + b];
-                    gi =  COEFF1 * s_re[p0 * SPEC_LD + b];
-                    gr -= COEFF2 * s_im[p2 * SPEC_LD + b];
-                    gi += COEFF2 * s_re[p2 * SPEC_LD + b];
-                    gr += COEFF2 * s_im[p4 * SPEC_LD + b];
-                    gi -= COEFF2 * s_re[p4 * SPEC_LD + b];
-                    gr += COEFF1 * s_im[p6 * SPEC_LD + b];
-                    gi -= COEFF1 * s_re[p6 * SPEC_LD + b];
-                    const float dr = s_re[sD * SPEC_LD + b] * 0.5f, di = s_im[sD * SPEC_LD + b] * 0.5f;
-                    /* lower half-band (odd band index) of bins 1,3 subtracts, of bins 2,4 adds (afSTFT_internal.c:606-619) */
-                    const bool lower = (band & 1) != 0;
-                    const bool minus = ((b & 1) != 0) == lower;
-                    v = minus ? make_float2(dr - gr, di - gi) : make_float2(dr + gr, di + gi);
+                    if (k != 64) outBase[(unsigned)(132 - k) * ob32 + o] = Xm;         /* bins 5..128 -> bands 9..132 */
+                    if (k == 0 || k >= 5) {
+                        outBase[(unsigned)(k == 0 ? 0 : k + 4) * ob32 + o] = Xk;
+                    } else {
+                        int p2 = pos - 2; if (p2 < 0) p2 += ARING;
+                        int p4 = pos - 4; if (p4 < 0) p4 += ARING;
+                        int p6 = pos - 6; if (p6 < 0) p6 += ARING;
+                        const float2 S0 = ana_bin_lo(ring + pos * SLOT, k, W);
+                        const float2 S2 = ana_bin_lo(ring + p2 * SLOT, k, W);
+                        const float2 S4 = ana_bin_lo(ring + p4 * SLOT, k, W);
+                        const float2 S6 = ana_bin_lo(ring + p6 * SLOT, k, W);
+                        float gr, gi;
+                        gr = -COEFF1 * S0.y;          gi = COEFF1 * S0.x;
+                        gr -= COEFF2 * S2.y;          gi += COEFF2 * S2.x;
+                        gr += COEFF2 * S4.y;          gi -= COEFF2 * S4.x;
+                        gr += COEFF1 * S6.y;          gi -= COEFF1 * S6.x;
+                        const float dr = Xk.x * 0.5f, di = Xk.y * 0.5f;
+                        /* lower half-band (band 2k-1) of bins 1,3 subtracts, of bins 2,4 adds (afSTFT_internal.c:606-619) */
+                        const float sgn = (k & 1) ? -1.0f : 1.0f;
+                        outBase[(unsigned)(2 * k - 1) * ob32 + o] = make_float2(dr + sgn * gr, di + sgn * gi);
+                        outBase[(unsigned)(2 * k) * ob32 + o] = make_float2(dr - sgn * gr, di - sgn * gi);
+                    }
                 }
-                g.a.out[(long long)inst * g.a.out_inst + (long long)band * g.a.out_band + (long long)ch * g.a.out_ch + hop] = v;
             }
         }
-        s0 += n;
-        __syncthreads();
+        p0 += n; if (p0 >= ARING) p0 -= ARING;
+        lds_barrier();
     }
 
-    /* the workgroup that owns the last chunk records the new input history */
-    if (c1 == g.a.H && g.a.hist_wr) {
-        for (int idx = tid; idx < SAF_ANA_HIST * 32; idx += 256) {
-            const int row = idx >> 5, c4 = idx & 31;
-            const int hop = g.a.H - SAF_ANA_HIST + row;
-            float4 v = ana_load4(g, inst, ch, srcch, valid, scale, hop, c4);
-            float* p = g.a.hist_wr + (((long long)inst * g.a.nCh + ch) * SAF_ANA_HIST + row) * SAF_HOP + c4 * 4;
-            *reinterpret_cast<float4*>(p) = v;
+    /* the workgroup that owns the last chunk records the new input history: the last 15 input hops */
+    if (c1 == g.a.H && (g.a.H % SUB) != 0 && g.a.hist_wr && fOn) {        /* partial last sub-chunk: reload */
+        int hh = g.a.H - SAF_ANA_HIST < 0 ? 0 : g.a.H - SAF_ANA_HIST;
+        int fr = hh / T, sb = hh - fr * T;
+        long long off = (long long)fr * g.a.in_frame + sb * SAF_HOP;
+        float* dst = g.a.hist_wr + ((long long)inst * g.a.nCh + fch) * SAF_ANA_HIST * SAF_HOP + fn;
+#pragma unroll
+        for (int row = 0; row < SAF_ANA_HIST; row++) {
+            const int h = g.a.H - SAF_ANA_HIST + row;
+            const float* base = h < 0 ? histBase + (SAF_ANA_HIST + h) * SAF_HOP : inBase + off;
+            const unsigned o = h < 0 ? offHist : offIn;
+            dst[row * SAF_HOP] = base[o] * (h < 0 ? 1.0f : scale);
+            if (h >= 0) { sb++; off += SAF_HOP; if (sb == T) { sb = 0; off += g.a.in_frame - (long long)T * SAF_HOP; } }
         }
     }
 }
@@ -239,99 +359,144 @@ __global__ __launch_bounds__(256) void afstft_analysis_kernel(AnaArgs g)
 struct SynArgs {
     SynLaunch s;
     const float* win;
-    const float2* tw;
+    const float2* twJ;
+    const float2* tw256;
 };
 
-__device__ __forceinline__ int g_pad(int n) { return n + 4 * (n >> 5); }
-
-__global__ __launch_bounds__(256) void afstft_synthesis_kernel(SynArgs g)
+__global__ __launch_bounds__(256, 2) void afstft_synthesis_kernel(SynArgs g)
 {
-    __shared__ float s_re[SUB * SPEC_LD];
-    __shared__ float s_im[SUB * SPEC_LD];
-    __shared__ __attribute__((aligned(16))) float s_g[SUB * G_LD];
+    __shared__ __attribute__((aligned(16))) float s_ring[2 * SUB * SLOT];
+    __shared__ float2 s_tw256[130];
+    __shared__ float2 s_twJ[8 * 16];       /* the overlap-add keeps frame history in registers: twiddles live in LDS here */
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ch = blockIdx.x, inst = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int chBase = blockIdx.x * 2, inst = blockIdx.y;
     const int H = g.s.H;
-    const LaneTw tw = load_tw(g.tw, lane);
-    const int q = bitrev6(lane);
+    for (int k = tid; k < 129; k += 256) s_tw256[k] = g.tw256[k];
+    if (tid < 128) s_twJ[tid] = g.twJ[tid];
 
-    /* overlap-add state of thread n (<128): the last 9 synthesised frames at n (first half) and 128+n (second half) */
-    float gl[10], gr[10], wn[10];
-    if (tid < 128) {
+    /* overlap-add role: thread = (channel of the pair, sample position n): gl[i] / gr[i] = samples n / 128+n of the
+     * frame synthesised at hop h0 - 9 + i */
+    const int oc = tid >> 7, on = tid & 127;
+    const int och = chBase + oc;
+    const bool oOn = och < g.s.nCh;
+    float wn[10], gl[OLA + 9], gr[OLA + 9];     /* OLA = hops per overlap-add pass (static register window) */
 #pragma unroll
-        for (int k = 0; k < 10; k++) wn[k] = g.win[k * SAF_HOP + tid];
-        const float* h = g.s.hist_rd + ((long long)inst * g.s.nCh + ch) * SAF_SYN_HIST * 256;
+    for (int k = 0; k < 10; k++) wn[k] = g.win[k * SAF_HOP + on];
+    {
+        const float* h = g.s.hist_rd + ((long long)inst * g.s.nCh + (oOn ? och : 0)) * SAF_SYN_HIST * 256;
 #pragma unroll
-        for (int k = 1; k < 10; k++) { gl[k] = h[(9 - k) * 256 + tid]; gr[k] = h[(9 - k) * 256 + 128 + tid]; }
-        gl[0] = gr[0] = 0.f;
+        for (int i = 0; i < 9; i++) { gl[i] = h[i * 256 + on]; gr[i] = h[i * 256 + 128 + on]; }
+#pragma unroll
+        for (int i = 9; i < OLA + 9; i++) gl[i] = gr[i] = 0.0f;
     }
+    const int ff = tid >> 3, fj = tid & 7;
+    const int fftC = ff >> 4, fftT = ff & 15;
+    const float2* twJ = s_twJ + fj * 16;
+
+    const float2* inBase = g.s.in + (long long)inst * g.s.in_inst + (long long)chBase * g.s.in_ch;
+    const unsigned ib32 = (unsigned)g.s.in_band, ic32 = (unsigned)g.s.in_ch;
+    const int gt = tid & 15, gr_ = tid >> 4;
+    const int nC = g.s.nCh - chBase >= 2 ? 2 : 1;
+    const int T = g.s.hopsPerFrame;
+    float* outBase = g.s.out + (long long)inst * g.s.out_inst + (long long)(oOn ? och : 0) * g.s.out_ch + on;
+    int oFrame = 0, oSub = 0;                         /* output cursor (uniform): hop -> (frame, hop within the frame) */
 
     for (int s0 = 0; s0 < H; s0 += SUB) {
         const int n = min(SUB, H - s0);
-        /* gather bands -> bins (afHybridInverse, afSTFT_internal.c:625-653): reads are time-contiguous */
-        for (int idx = tid; idx < SAF_NBINS * SUB; idx += 256) {
-            const int bin = idx >> 4, t = idx & 15;
-            if (t >= n) continue;
-            const float2* p = g.s.in + (long long)inst * g.s.in_inst + (long long)ch * g.s.in_ch + (s0 + t);
-            float2 v;
-            if (bin == 0) v = p[0];
-            else if (!g.s.hybrid) v = p[(long long)bin * g.s.in_band];
-            else if (bin < 5) {
-                const float2 a = p[(long long)(2 * bin - 1) * g.s.in_band], b = p[(long long)(2 * bin) * g.s.in_band];
-                v = make_float2(a.x + b.x, a.y + b.y);
-            } else v = p[(long long)(bin + 4) * g.s.in_band];
-            /* low-delay mode: odd bins change sign = circular half-frame shift (afSTFT_internal.c:366-369) */
-            if (g.s.lowDelay && (bin & 1) && bin < SAF_HOP) { v.x = -v.x; v.y = -v.y; }
-            s_re[t * SPEC_LD + bin] = v.x;
-            s_im[t * SPEC_LD + bin] = v.y;
-        }
-        __syncthreads();
-        for (int t = wave; t < n; t += 4) {
-            const float* re = &s_re[t * SPEC_LD];
-            const float* im = &s_im[t * SPEC_LD];
-            /* half-complex -> packed: Z[k], Z[128-k] from X[k], X[128-k]  (kiss_fftr.c:125-161); Im of DC/Nyquist ignored */
-            const int k = lane;
-            const float2 fk = make_float2(re[k], im[k]);
-            const float2 fnkc = make_float2(re[128 - k], -im[128 - k]);
-            const float2 fek = make_float2(fk.x + fnkc.x, fk.y + fnkc.y);
-            const float2 tmp = make_float2(fk.x - fnkc.x, fk.y - fnkc.y);
-            const float2 fok = cmulc(tmp, tw.w256);                         /* * e^{+2 pi i k/256} */
-            float2 Zk = make_float2(fek.x - fok.y, fek.y + fok.x);          /* fek + i fok */
-            float2 Zmk = make_float2(fek.x + fok.y, -(fek.y - fok.x));      /* conj(fek - i fok) */
-            if (lane == 0) {
-                Zk = make_float2(re[0] + re[128], re[0] - re[128]);
-                Zmk = make_float2(2.0f * re[64], -2.0f * im[64]);            /* Z[64] = 2 conj(X[64]) */
+        lds_barrier();
+        /* 1. gather bands -> bins (afHybridInverse, afSTFT_internal.c:625-653) with time-contiguous reads, and
+         *    half-complex -> packed (kiss_fftr.c:125-161; Im of DC/Nyquist ignored): bins k and 128-k give
+         *    2 Z[k] = E + i O and 2 Z[128-k] = conj(E - i O), E = X[k] + conj X[128-k], O = (X[k] - conj X[128-k]) e^{+2 pi i k/256} */
+        if (gt < n) {
+            const unsigned ohop = (unsigned)(s0 + gt);
+            /* all loads of the sub-chunk are issued before the first use: the gather is bound by bytes in flight */
+            /* all loads of the sub-chunk are issued before the first use: the gather is bound by bytes in flight */
+            float2 vXk[9], vXm[9], vX2[2];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                int item = gr_ + 16 * i; if (item >= 65 * nC) item = 0;
+                const int c = item >= 65 ? 1 : 0;
+                const int k = item - 65 * c;
+                const unsigned o = (unsigned)c * ic32 + ohop;
+                int bk, bm;
+                if (!g.s.hybrid) { bk = k; bm = 128 - k; }
+                else { bm = 132 - k; bk = k == 0 ? 0 : (k < 5 ? 2 * k - 1 : k + 4); }      /* bin k = band 2k-1 (+ band 2k), k = 1..4 */
+                vXk[i] = inBase[(unsigned)bk * ib32 + o];
+                vXm[i] = inBase[(unsigned)bm * ib32 + o];
+                if (i == 0 || i == 4) {          /* the only passes that can hold bins 1..4 (items 1..4 and 66..69) */
+                    const bool pair = g.s.hybrid && k >= 1 && k < 5;
+                    const float2 u = inBase[(unsigned)(pair ? 2 * k : bk) * ib32 + o];
+                    vX2[i >> 2] = pair ? u : make_float2(0.f, 0.f);
+                }
             }
-            float2 a = Zk;
-            float2 b = shfl(Zmk, (64 - lane) & 63);                          /* Z[lane + 64] */
-            fft128_inv(a, b, tw, lane);
-            const float sc = 1.0f / 256.0f;                                  /* saf_rfft_backward scaling (saf_utility_fft.c:751) */
-            float4 o = make_float4(a.x * sc, a.y * sc, b.x * sc, b.y * sc); /* frame samples 4q .. 4q+3 */
-            *reinterpret_cast<float4*>(&s_g[t * G_LD + g_pad(4 * q)]) = o;
-        }
-        __syncthreads();
-        if (tid < 128) {
-            for (int t = 0; t < n; t++) {
-                gl[0] = s_g[t * G_LD + g_pad(tid)];
-                gr[0] = s_g[t * G_LD + g_pad(128 + tid)];
-                /* 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444) */
-                float acc = 0.f;
 #pragma unroll
-                for (int k = 9; k >= 0; k--) acc = fmaf(wn[k], (k & 1) ? gr[k] : gl[k], acc);
-                const int hop = s0 + t;
-                const int frame = hop / g.s.hopsPerFrame, sub = hop - frame * g.s.hopsPerFrame;
-                g.s.out[(long long)inst * g.s.out_inst + (long long)frame * g.s.out_frame + (long long)ch * g.s.out_ch + sub * SAF_HOP + tid] = acc;
-#pragma unroll
-                for (int k = 9; k >= 1; k--) { gl[k] = gl[k - 1]; gr[k] = gr[k - 1]; }
+            for (int i = 0; i < 9; i++) {
+                const int item = gr_ + 16 * i;
+                if (item < 65 * nC) {
+                    const int c = item >= 65 ? 1 : 0;
+                    const int k = item - 65 * c;
+                    float2 Xk = vXk[i], Xm = vXm[i];
+                    if (i == 0 || i == 4) { Xk.x += vX2[i >> 2].x; Xk.y += vX2[i >> 2].y; }
+                    /* low-delay mode: odd bins change sign = circular half-frame shift (afSTFT_internal.c:366-369) */
+                    if (g.s.lowDelay && (k & 1)) { Xk.x = -Xk.x; Xk.y = -Xk.y; Xm.x = -Xm.x; Xm.y = -Xm.y; }
+                    if (k == 0) { Xk.y = 0.0f; Xm.y = 0.0f; }
+                    const float2 E = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);
+                    const float2 D = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);
+                    const float2 W = s_tw256[k];
+                    const float2 O = make_float2(D.x * W.x + D.y * W.y, D.y * W.x - D.x * W.y);      /* D * conj(W) */
+                    float* slot = s_ring + (c * SUB + gt) * SLOT;
+                    *reinterpret_cast<float2*>(slot + 2 * k) = make_float2(E.x - O.y, E.y + O.x);
+                    if (k != 0 && k != 64) *reinterpret_cast<float2*>(slot + 2 * (128 - k)) = make_float2(E.x + O.y, O.x - E.y);
+                }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        /* 2. 128-point inverse FFT in place: frame sample 2m, 2m+1 = Re, Im z[m] (x 1/256 in the overlap-add:
+         *    1/2 of the packing above and the 1/128 of saf_rfft_backward's 1/N, saf_utility_fft.c:751) */
+        if (fftT < n) fft128_slot<true>(s_ring + (fftC * SUB + fftT) * SLOT, fj, twJ);
+        lds_barrier();
+        /* 3. 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0+t is
+         *    sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n] */
+        {
+            const float sc = 1.0f / 256.0f;
+#pragma unroll
+            for (int half = 0; half < SUB / OLA; half++) {
+                const int nh = min(OLA, n - half * OLA);          /* hops of this pass (<= 0: nothing left) */
+                if (nh <= 0) break;
+#pragma unroll
+                for (int u = 0; u < OLA; u++) {
+                    if (u < nh) {
+                        const int t = half * OLA + u;
+                        const float* slot = s_ring + (oc * SUB + t) * SLOT;
+                        gl[9 + u] = slot[on] * sc; gr[9 + u] = slot[128 + on] * sc;
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int k = 9; k >= 0; k--) acc = fmaf(wn[k], (k & 1) ? gr[9 + u - k] : gl[9 + u - k], acc);
+                        if (oOn) outBase[(long long)oFrame * g.s.out_frame + oSub * SAF_HOP] = acc;
+                        oSub++; if (oSub == T) { oSub = 0; oFrame++; }
+                    }
+                }
+                /* slide the window: the 9 newest frames sit at indices nh .. nh+8 */
+                if (nh == OLA) {
+#pragma unroll
+                    for (int i = 0; i < 9; i++) { gl[i] = gl[i + OLA]; gr[i] = gr[i + OLA]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        float a = gl[i], b = gr[i];
+#pragma unroll
+                        for (int q = 1; q < OLA; q++) if (q == nh) { a = gl[i + q]; b = gr[i + q]; }
+                        gl[i] = a; gr[i] = b;
+                    }
+                }
+            }
+        }
     }
-    if (tid < 128 && g.s.hist_wr) {
-        float* h = g.s.hist_wr + ((long long)inst * g.s.nCh + ch) * SAF_SYN_HIST * 256;
+    if (oOn && g.s.hist_wr) {
+        float* h = g.s.hist_wr + ((long long)inst * g.s.nCh + och) * SAF_SYN_HIST * 256;
 #pragma unroll
-        for (int k = 1; k < 10; k++) { h[(9 - k) * 256 + tid] = gl[k]; h[(9 - k) * 256 + 128 + tid] = gr[k]; }
+        for (int i = 0; i < 9; i++) { h[i * 256 + on] = gl[i]; h[i * 256 + 128 + on] = gr[i]; }
     }
 }
 
@@ -360,23 +525,21 @@ const float* dev_window(int lowDelay, int synthesis)
     return d;
 }
 
+/* [0 .. 127]: twJ[j][p] = exp(-2 pi i j p / 128), j < 8, p < 16;  [128 .. 256]: exp(-2 pi i k / 256), k <= 128 */
 const float2* dev_twiddles()
 {
     if (g_dev_tw) return g_dev_tw;
-    std::vector<float2> t(8 * 64);
-    for (int s = 0; s < 6; s++) {
-        const int h = 1 << s;
-        for (int l = 0; l < 64; l++) {
-            const double a = -2.0 * SAF_PId * (double)(l & (h - 1)) / (double)(2 * h);
-            t[s * 64 + l] = make_float2((float)cos(a), (float)sin(a));
+    std::vector<float2> t(128 + 129);
+    for (int j = 0; j < 8; j++)
+        for (int p = 0; p < 16; p++) {
+            const double a = -2.0 * SAF_PId * (double)(j * p) / 128.0;
+            t[j * 16 + p] = make_float2((float)cos(a), (float)sin(a));
         }
+    for (int k = 0; k <= 128; k++) {
+        const double a = -2.0 * SAF_PId * (double)k / 256.0;
+        t[128 + k] = make_float2((float)cos(a), (float)sin(a));
     }
-    for (int l = 0; l < 64; l++) {
-        double a = -2.0 * SAF_PId * (double)l / 128.0;
-        t[6 * 64 + l] = make_float2((float)cos(a), (float)sin(a));
-        a = -2.0 * SAF_PId * (double)l / 256.0;
-        t[7 * 64 + l] = make_float2((float)cos(a), (float)sin(a));
-    }
+    t[128 + 128] = make_float2(-1.0f, 0.0f);           /* exact: bin 128 must come out purely real */
     HIP_CHECK(hipMalloc((void**)&g_dev_tw, t.size() * sizeof(float2)));
     HIP_CHECK(hipMemcpy(g_dev_tw, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
     return g_dev_tw;
@@ -385,20 +548,31 @@ const float2* dev_twiddles()
 void launch_analysis(const AnaLaunch& a)
 {
     if (a.H <= 0 || a.nCh <= 0 || a.nInst <= 0) return;
-    if ((a.in_inst | a.in_ch | a.in_frame) & 3) SAF_FATAL("analysis: sample strides must be multiples of 4 floats");
-    if (((uintptr_t)a.in & 15) != 0) SAF_FATAL("analysis: input must be 16-byte aligned");
     AnaArgs g;
     g.a = a;
     g.win = dev_window(a.lowDelay, 0);
-    g.tw = dev_twiddles();
-    /* time chunks add parallelism when few (instance, channel) pairs are in flight; each extra chunk
-     * recomputes 6 warm-up FFTs, so long launches use long chunks */
-    const long long pairs = (long long)a.nCh * a.nInst;
+    g.twJ = dev_twiddles();
+    g.tw256 = g.twJ + 128;
+    /* Time chunks add parallelism when few (instance, channel pair) workgroups are in flight, but every extra chunk
+     * recomputes 6 warm-up FFTs.  Chunks are multiples of 16 hops (aligned 128-byte row segments).  Pick the chunk
+     * count that minimises (rounds over the chip) x (sub-chunks per workgroup); 3 workgroups per CU on 256 CUs. */
+    const long long groups = (long long)((a.nCh + 1) / 2) * a.nInst;
+    const long long slots = 3 * 256;
     int chunk = a.H;
-    if (pairs < 2048 && a.H > 32) chunk = 32;
-    if (pairs < 512 && a.H > 16) chunk = 16;
+    {
+        long long best = -1;
+        const int nSub = (a.H + SUB - 1) / SUB;
+        for (int per = nSub; per >= 1; per--) {                 /* sub-chunks per workgroup */
+            const int nc = (nSub + per - 1) / per;
+            const long long rounds = (groups * nc + slots - 1) / slots;
+            const long long cost = rounds * (3 * per + 1);      /* prologue ~ a third of a sub-chunk */
+            if (best < 0 || cost < best) { best = cost; chunk = per * SUB; }
+        }
+    }
     g.chunk = chunk;
-    dim3 grid((a.H + chunk - 1) / chunk, a.nCh, a.nInst);
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SAF_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+    { static int fc = -1; if (fc < 0) { const char* e = getenv("SAF_CHUNK"); fc = e ? atoi(e) : 0; } if (fc > 0) g.chunk = fc; }
+    dim3 grid((a.H + g.chunk - 1) / g.chunk, (a.nCh + 1) / 2, a.nInst);
     KernelTimer kt("afstft_analysis");
     hipLaunchKernelGGL(afstft_analysis_kernel, grid, dim3(256), 0, stream(), g);
     HIP_CHECK(hipGetLastError());
@@ -410,8 +584,9 @@ void launch_synthesis(const SynLaunch& s)
     SynArgs g;
     g.s = s;
     g.win = dev_window(s.lowDelay, 1);
-    g.tw = dev_twiddles();
-    dim3 grid(s.nCh, s.nInst);
+    g.twJ = dev_twiddles();
+    g.tw256 = g.twJ + 128;
+    dim3 grid((s.nCh + 1) / 2, s.nInst);
     KernelTimer kt("afstft_synthesis");
     hipLaunchKernelGGL(afstft_synthesis_kernel, grid, dim3(256), 0, stream(), g);
     HIP_CHECK(hipGetLastError());
