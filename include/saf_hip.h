@@ -290,6 +290,91 @@ SAF_API void saf_hip_matrixConv_setMaxBlocksPerCall(int nBlocks);
 SAF_API void saf_hip_matrixConv_apply_dev(void* const hMC, const float* d_in, long long in_ch_stride, long long in_block_stride,
                                           float* d_out, long long out_ch_stride, long long out_block_stride, int nBlocks);
 
+/* ========================================================================== */
+/*      HRIR processing (saf_hrir.h) and Voronoi weights (saf_utility_geometry.h) */
+/* ========================================================================== */
+SAF_API void estimateITDs(float* hrirs, int N_dirs, int hrir_len, int fs, float* itds_s);                                              /* saf_hrir.h:94 / saf_hrir.c:40 */
+SAF_API void HRIRs2HRTFs_afSTFT(float* hrirs, int N_dirs, int hrir_len, int hopsize, int LDmode, int hybridmode, float_complex* hrtf_fb); /* saf_hrir.h:113 / saf_hrir.c:110 */
+SAF_API void diffuseFieldEqualiseHRTFs(int N_dirs, float* itds_s, float* centreFreq, int N_bands, float* weights, int applyEQ, int applyPhase, float_complex* hrtfs); /* saf_hrir.h:186 / saf_hrir.c:173 */
+SAF_API void getVoronoiWeights(float* dirs_deg, int nDirs, int diagFLAG, float* weights);                                              /* saf_utility_geometry.h:430 / .c:937 */
+/** Installs the HRIR set used wherever the reference would read its built-in default set (__default_hrirs & co.,
+ *  saf_hrir.h:49-61; the data file is absent from the reference checkout, so this library ships none).
+ *  hrirs: N x 2 x len, dirs: N x 2 [azimuth, elevation] degrees.  Copied; applies to codecs initialised afterwards. */
+SAF_API void saf_hip_setDefaultHRIRs(const float* hrirs, const float* hrir_dirs_deg, int N_hrir_dirs, int hrir_len, int hrir_fs);
+
+/* ========================================================================== */
+/*      binauraliser (examples/include/binauraliser.h:73-376)                 */
+/* ========================================================================== */
+typedef enum { INTERP_TRI = 1, INTERP_TRI_PS } INTERP_MODES;                     /* binauraliser.h:58-61 */
+/** The reference fixes the block size (-DBINAURALISER_FRAME_SIZE, default 128) and the source cap (MAX_NUM_INPUTS = 64)
+ *  at compile time; here both are process-wide settings read by binauraliser_create. */
+SAF_API void saf_hip_binauraliser_setFrameSize(int frameSize);
+SAF_API void saf_hip_binauraliser_setMaxNumSources(int maxSources);
+
+SAF_API void binauraliser_create(void** const phBin);                            /* binauraliser.h:73 */
+SAF_API void binauraliser_destroy(void** const phBin);                           /* binauraliser.h:80 */
+SAF_API void binauraliser_init(void* const hBin, int samplerate);                /* binauraliser.h:90 */
+SAF_API void binauraliser_initCodec(void* const hBin);                           /* binauraliser.h:108 */
+SAF_API void binauraliser_process(void* const hBin, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* binauraliser.h:120 */
+SAF_API void binauraliser_refreshSettings(void* const hBin);                     /* binauraliser.h:136 */
+SAF_API void binauraliser_setSourceAzi_deg(void* const hBin, int index, float newAzi_deg);   /* binauraliser.h:139 */
+SAF_API void binauraliser_setSourceElev_deg(void* const hBin, int index, float newElev_deg); /* binauraliser.h:144 */
+SAF_API void binauraliser_setNumSources(void* const hBin, int new_nSources);     /* binauraliser.h:149 */
+SAF_API void binauraliser_setUseDefaultHRIRsflag(void* const hBin, int newState);/* binauraliser.h:159 */
+SAF_API void binauraliser_setSofaFilePath(void* const hBin, const char* path);   /* binauraliser.h:172 */
+SAF_API void binauraliser_setEnableHRIRsDiffuseEQ(void* const hBin, int newState);/* binauraliser.h:175 */
+SAF_API void binauraliser_setInputConfigPreset(void* const hBin, int newPresetID);/* binauraliser.h:178 */
+SAF_API void binauraliser_setEnableRotation(void* const hBin, int newState);     /* binauraliser.h:181 */
+SAF_API void binauraliser_setYaw(void* const hBin, float newYaw);                /* binauraliser.h:184 */
+SAF_API void binauraliser_setPitch(void* const hBin, float newPitch);            /* binauraliser.h:187 */
+SAF_API void binauraliser_setRoll(void* const hBin, float newRoll);              /* binauraliser.h:190 */
+SAF_API void binauraliser_setFlipYaw(void* const hBin, int newState);            /* binauraliser.h:196 */
+SAF_API void binauraliser_setFlipPitch(void* const hBin, int newState);          /* binauraliser.h:202 */
+SAF_API void binauraliser_setFlipRoll(void* const hBin, int newState);           /* binauraliser.h:208 */
+SAF_API void binauraliser_setRPYflag(void* const hBin, int newState);            /* binauraliser.h:214 */
+SAF_API void binauraliser_setInterpMode(void* const hBin, int newMode);          /* binauraliser.h:217 */
+SAF_API void binauraliser_setSourceGain(void* const hBin, int srcIdx, float newGain); /* binauraliser.h:222 */
+SAF_API void binauraliser_setSourceSolo(void* const hBin, int srcIdx);           /* binauraliser.h:227 */
+SAF_API void binauraliser_setUnSolo(void* const hBin);                           /* binauraliser.h:232 */
+SAF_API int  binauraliser_getFrameSize(void);                                    /* binauraliser.h:243 */
+SAF_API CODEC_STATUS binauraliser_getCodecStatus(void* const hBin);              /* binauraliser.h:246 */
+SAF_API float binauraliser_getProgressBar0_1(void* const hBin);                  /* binauraliser.h:253 */
+SAF_API void binauraliser_getProgressBarText(void* const hBin, char* text);      /* binauraliser.h:261 */
+SAF_API float binauraliser_getSourceAzi_deg(void* const hBin, int index);        /* binauraliser.h:264 */
+SAF_API float binauraliser_getSourceElev_deg(void* const hBin, int index);       /* binauraliser.h:267 */
+SAF_API int  binauraliser_getNumSources(void* const hBin);                       /* binauraliser.h:270 */
+SAF_API int  binauraliser_getMaxNumSources(void);                                /* binauraliser.h:273 */
+SAF_API int  binauraliser_getNumEars(void);                                      /* binauraliser.h:276 */
+SAF_API int  binauraliser_getNDirs(void* const hBin);                            /* binauraliser.h:279 */
+SAF_API int  binauraliser_getNTriangles(void* const hBin);                       /* binauraliser.h:285 */
+SAF_API float binauraliser_getHRIRAzi_deg(void* const hBin, int index);          /* binauraliser.h:288 */
+SAF_API float binauraliser_getHRIRElev_deg(void* const hBin, int index);         /* binauraliser.h:291 */
+SAF_API int  binauraliser_getHRIRlength(void* const hBin);                       /* binauraliser.h:294 */
+SAF_API int  binauraliser_getHRIRsamplerate(void* const hBin);                   /* binauraliser.h:297 */
+SAF_API int  binauraliser_getUseDefaultHRIRsflag(void* const hBin);              /* binauraliser.h:307 */
+SAF_API char* binauraliser_getSofaFilePath(void* const hBin);                    /* binauraliser.h:319 */
+SAF_API int  binauraliser_getEnableHRIRsDiffuseEQ(void* const hBin);             /* binauraliser.h:325 */
+SAF_API int  binauraliser_getDAWsamplerate(void* const hBin);                    /* binauraliser.h:328 */
+SAF_API int  binauraliser_getEnableRotation(void* const hBin);                   /* binauraliser.h:334 */
+SAF_API float binauraliser_getYaw(void* const hBin);                             /* binauraliser.h:337 */
+SAF_API float binauraliser_getPitch(void* const hBin);                           /* binauraliser.h:340 */
+SAF_API float binauraliser_getRoll(void* const hBin);                            /* binauraliser.h:343 */
+SAF_API int  binauraliser_getFlipYaw(void* const hBin);                          /* binauraliser.h:349 */
+SAF_API int  binauraliser_getFlipPitch(void* const hBin);                        /* binauraliser.h:355 */
+SAF_API int  binauraliser_getFlipRoll(void* const hBin);                         /* binauraliser.h:361 */
+SAF_API int  binauraliser_getRPYflag(void* const hBin);                          /* binauraliser.h:367 */
+SAF_API int  binauraliser_getInterpMode(void* const hBin);                       /* binauraliser.h:370 */
+SAF_API int  binauraliser_getProcessingDelay(void);                              /* binauraliser.h:376 */
+/** Device-pointer entry: nFrames consecutive blocks, in[frame*in_frame_stride + ch*in_ch_stride + n], two output rows
+ *  out[frame*out_frame_stride + ear*out_ch_stride + n].  State carries over exactly as between binauraliser_process calls. */
+SAF_API void saf_hip_binauraliser_process_dev(void* const hBin, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                              float* d_out, long long out_frame_stride, long long out_ch_stride, int nFrames);
+/** Read-back of the tables binauraliser_data holds (binauraliser_internal.h:95-118), for parity checks. */
+SAF_API void saf_hip_binauraliser_getITDs(void* const hBin, float* itds_s);
+SAF_API void saf_hip_binauraliser_getWeights(void* const hBin, float* weights);
+SAF_API void saf_hip_binauraliser_getHRTFfb(void* const hBin, float_complex* hrtf_fb);        /* [133][2][N] */
+SAF_API void saf_hip_binauraliser_getHRTFinterp(void* const hBin, float_complex* hrtf_interp);/* [nSources][133][2] */
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ vp = C.c_void_p
 
 def build(force=False):
     so = HERE / "libsaf_oracle.so"
-    srcs = [HERE / n for n in ("orc_core.c", "orc_sh.c", "orc_examples.c", "saf_oracle.h")]
+    srcs = [HERE / n for n in ("orc_core.c", "orc_sh.c", "orc_examples.c", "orc_binaural.c", "saf_oracle.h")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.check_call(["make", "-s", "-C", str(HERE)])
     if Path("/root/reference/framework/resources/kissFFT/kiss_fftr.c").exists():
@@ -352,3 +352,77 @@ class KissRef:
         out = np.zeros(self.N, np.float32)
         self.L.kiss_fftri(self.inv, X.ctypes.data_as(vp), fptr(out))
         return out * np.float32(1.0 / self.N)
+
+
+# ------------------------------------------------------------------ HRIR processing / binauraliser
+def estimateITDs(hrirs, fs):
+    hrirs = np.ascontiguousarray(hrirs, np.float32)
+    N, _, L = hrirs.shape
+    out = np.zeros(N, np.float32)
+    lib().orc_estimateITDs(fptr(hrirs), N, L, fs, fptr(out))
+    return out
+
+
+def getVoronoiWeights(dirs_deg):
+    d = np.ascontiguousarray(dirs_deg, np.float32)
+    out = np.zeros(d.shape[0], np.float32)
+    lib().orc_getVoronoiWeights(fptr(d), d.shape[0], fptr(out))
+    return out
+
+
+def diffuseFieldEqualiseHRTFs(hrtfs, weights=None):
+    """hrtfs [nBands][2][N] complex64 -> equalised copy."""
+    h = np.ascontiguousarray(hrtfs, np.complex64).copy()
+    nB, _, N = h.shape
+    w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+    lib().orc_diffuseFieldEqualiseHRTFs(N, nB, fptr(w) if w is not None else None, h.ctypes.data_as(vp))
+    return h
+
+
+class Binauraliser:
+    def __init__(self, frameSize=128, maxSources=64):
+        self.h = vp()
+        self.F = frameSize
+        self.maxSources = maxSources
+        L = lib()
+        L.orc_binauraliser_create(C.byref(self.h), frameSize, maxSources)
+        for n in ("getITDs", "getWeights"):
+            getattr(L, "orc_binauraliser_" + n).restype = c_f
+        for n in ("getHRTFfb", "getHRTFinterp"):
+            getattr(L, "orc_binauraliser_" + n).restype = vp
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_binauraliser_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def setHRIRs(self, hrirs, dirs_deg, fs):
+        hrirs = np.ascontiguousarray(hrirs, np.float32); d = np.ascontiguousarray(dirs_deg, np.float32)
+        lib().orc_binauraliser_setHRIRs(self.h, fptr(hrirs), fptr(d), hrirs.shape[0], hrirs.shape[2], fs)
+
+    def process(self, x, nOut=2, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.zeros((nOut, self.F), np.float32)
+        lib().orc_binauraliser_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, ns)
+        return y
+
+    def itds(self):
+        n = lib().orc_binauraliser_getNDirs(self.h)
+        return np.ctypeslib.as_array(lib().orc_binauraliser_getITDs(self.h), shape=(n,)).copy()
+
+    def weights(self):
+        n = lib().orc_binauraliser_getNDirs(self.h)
+        return np.ctypeslib.as_array(lib().orc_binauraliser_getWeights(self.h), shape=(n,)).copy()
+
+    def hrtf_fb(self):
+        n = lib().orc_binauraliser_getNDirs(self.h)
+        p = C.cast(lib().orc_binauraliser_getHRTFfb(self.h), C.POINTER(C.c_float))
+        return np.ctypeslib.as_array(p, shape=(133, 2, n, 2)).copy().view(np.complex64)[..., 0]
+
+    def hrtf_interp(self, nSrc):
+        p = C.cast(lib().orc_binauraliser_getHRTFinterp(self.h), C.POINTER(C.c_float))
+        return np.ctypeslib.as_array(p, shape=(self.maxSources, 133, 2, 2)).copy().view(np.complex64)[:nSrc, ..., 0]
+
+    def __del__(self):
+        if self.h:
+            lib().orc_binauraliser_destroy(C.byref(self.h))

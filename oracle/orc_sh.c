@@ -799,3 +799,99 @@ void orc_getLoudspeakerDecoderMtx(const float* ls_dirs_deg, int nLS, int method,
         free(a_n);
     }
 }
+
+/* ========================================================================== */
+/*            spherical Voronoi integration weights (saf_utility_geometry.c)  */
+/* ========================================================================== */
+
+static void cross3f(const float* a, const float* b, float* c)        /* crossProduct3 (saf_utility_geometry.c:452-462) */
+{
+    c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
+}
+static float norm3f(const float* v) { return sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+/* getVoronoiWeights (saf_utility_geometry.c:937-983): sphDelaunay (:659-691, float trigonometry) -> sphVoronoi
+ * (:693-868: Voronoi vertex of a Delaunay triangle = its unit normal; triangles around a point ordered by walking
+ * through shared neighbours; vertices closer than 1e-5 per coordinate are merged) -> sphVoronoiAreas (:870-935:
+ * spherical excess of the polygon, interior angles from the tangents of the great circles).  The reference's
+ * quickhull is replaced by the deterministic hull of this file; the Voronoi cells do not depend on the face order. */
+void orc_getVoronoiWeights(const float* dirs_deg, int nDirs, float* weights)
+{
+    float* V = (float*)malloc(sizeof(float) * 3 * nDirs);
+    double* P = (double*)malloc(sizeof(double) * 3 * nDirs);
+    for (int i = 0; i < nDirs; i++) {
+        V[i * 3 + 2] = sinf(dirs_deg[i * 2 + 1] * ORC_PI / 180.0f);
+        const float rcoselev = cosf(dirs_deg[i * 2 + 1] * ORC_PI / 180.0f);
+        V[i * 3 + 0] = rcoselev * cosf(dirs_deg[i * 2 + 0] * ORC_PI / 180.0f);
+        V[i * 3 + 1] = rcoselev * sinf(dirs_deg[i * 2 + 0] * ORC_PI / 180.0f);
+        for (int k = 0; k < 3; k++) P[3 * i + k] = V[3 * i + k];
+    }
+    int* faces = NULL;
+    const int nFaces = sphere_hull(P, nDirs, &faces);
+    free(P);
+    for (int i = 0; i < nDirs; i++) weights[i] = 0.0f;
+    if (!faces) { free(V); return; }
+    /* Voronoi vertices */
+    float* vert = (float*)malloc(sizeof(float) * 3 * nFaces);
+    for (int n = 0; n < nFaces; n++) {
+        float r12[3], r13[3], nr[3];
+        for (int k = 0; k < 3; k++) { r12[k] = V[faces[n * 3 + 1] * 3 + k] - V[faces[n * 3] * 3 + k]; r13[k] = V[faces[n * 3 + 2] * 3 + k] - V[faces[n * 3] * 3 + k]; }
+        cross3f(r12, r13, nr);
+        const float inv = 1.0f / norm3f(nr);
+        for (int k = 0; k < 3; k++) vert[n * 3 + k] = nr[k] * inv;
+    }
+    int* dup = (int*)calloc(nFaces, sizeof(int));
+    for (int n = 0; n < nFaces; n++)
+        if (dup[n] == 0)
+            for (int m = 0; m < nFaces; m++)
+                if (n != m && fabsf(vert[n * 3] - vert[m * 3]) < 1.0e-5f && fabsf(vert[n * 3 + 1] - vert[m * 3 + 1]) < 1.0e-5f && fabsf(vert[n * 3 + 2] - vert[m * 3 + 2]) < 1.0e-5f)
+                    dup[m] = n;
+    int* ring = (int*)malloc(sizeof(int) * nFaces);
+    int* poly = (int*)malloc(sizeof(int) * nFaces);
+    float* theta = (float*)malloc(sizeof(float) * nFaces);
+    for (int n = 0; n < nDirs; n++) {
+        int nR = 0;
+        for (int m = 0; m < nFaces; m++) if (faces[m * 3] == n || faces[m * 3 + 1] == n || faces[m * 3 + 2] == n) ring[nR++] = m;
+        if (nR < 3) continue;
+        /* walk around the point: next triangle = the unvisited one sharing the current "outer" vertex */
+        int cur = ring[0], curv = -1, nS = 0;
+        for (int j = 0; j < 3; j++) if (faces[cur * 3 + j] != n) { curv = faces[cur * 3 + j]; break; }
+        poly[nS++] = cur;
+        while (nS < nR) {
+            int found = -1;
+            for (int l = 0; l < nR && found < 0; l++) {
+                const int f = ring[l];
+                if (f == cur) continue;
+                int seen = 0; for (int q = 0; q < nS; q++) if (poly[q] == f) seen = 1;
+                if (seen) continue;
+                if (faces[f * 3] == curv || faces[f * 3 + 1] == curv || faces[f * 3 + 2] == curv) found = f;
+            }
+            if (found < 0) break;
+            poly[nS++] = found;
+            for (int j = 0; j < 3; j++) if (faces[found * 3 + j] != n && faces[found * 3 + j] != curv) { curv = faces[found * 3 + j]; break; }
+            cur = found;
+        }
+        /* merge duplicate vertices, keeping first occurrences in walking order */
+        int nU = 0;
+        for (int i = 0; i < nS; i++) {
+            const int id = dup[poly[i]] != 0 ? dup[poly[i]] : poly[i];
+            int seen = 0; for (int q = 0; q < nU; q++) if (poly[q] == id) seen = 1;
+            if (!seen) poly[nU++] = id;
+        }
+        if (nU < 3) continue;
+        for (int k = 0; k < nU; k++) {
+            const float* r01 = &vert[poly[k] * 3]; const float* r02 = &vert[poly[(k + 1) % nU] * 3]; const float* r03 = &vert[poly[(k + 2) % nU] * 3];
+            float r2x1[3], r21[3], r2x3[3], r23[3];
+            cross3f(r02, r01, r2x1); cross3f(r2x1, r02, r21);
+            cross3f(r02, r03, r2x3); cross3f(r2x3, r02, r23);
+            const float n21 = 1.0f / norm3f(r21), n23 = 1.0f / norm3f(r23);
+            float d = 0.0f;
+            for (int q = 0; q < 3; q++) d += (r21[q] * n21) * (r23[q] * n23);
+            theta[k] = acosf(d);
+        }
+        float tmp = 0.0f;
+        for (int k = 0; k < nU; k++) tmp += theta[k];
+        weights[n] = tmp - ((float)nU - 2.0f) * ORC_PI;
+    }
+    free(V); free(faces); free(vert); free(dup); free(ring); free(poly); free(theta);
+}

@@ -128,6 +128,36 @@ void orc_matrixConv_apply(void* h, const float* in, float* out);
 void orc_binaural_mac(const orc_cpx* inTF /* [nBands][nSrcStride][T] */, const orc_cpx* hrtf /* [nSrc][nBands][2] */,
                       int nBands, int nSrc, int nSrcStride, int T, float scale, orc_cpx* outTF /* [nBands][2][T] */);
 
+/* ---- HRIR processing (saf_hrir.c) and spherical Voronoi weights (saf_utility_geometry.c:937) ---- */
+void orc_estimateITDs(const float* hrirs /* N x 2 x len */, int N_dirs, int hrir_len, int fs, float* itds_s);
+void orc_diffuseFieldEqualiseHRTFs(int N_dirs, int N_bands, const float* weights /* may be NULL */, orc_cpx* hrtfs /* bands x 2 x N */);
+void orc_getVoronoiWeights(const float* dirs_deg, int nDirs, float* weights);
+
+/* ---- binauraliser (examples/src/binauraliser); the HRIR set is injected (the reference's default set is absent) ---- */
+void orc_binauraliser_create(void** ph, int frameSize, int maxSources);
+void orc_binauraliser_destroy(void** ph);
+void orc_binauraliser_setHRIRs(void* h, const float* hrirs, const float* dirs_deg, int N, int len, int fs);
+void orc_binauraliser_init(void* h, int sampleRate);
+void orc_binauraliser_initCodec(void* h);
+void orc_binauraliser_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
+void orc_binauraliser_setSourceAzi_deg(void* h, int i, float v);
+void orc_binauraliser_setSourceElev_deg(void* h, int i, float v);
+void orc_binauraliser_setNumSources(void* h, int n);
+void orc_binauraliser_setEnableHRIRsDiffuseEQ(void* h, int s);
+void orc_binauraliser_setEnableRotation(void* h, int s);
+void orc_binauraliser_setYaw(void* h, float v);
+void orc_binauraliser_setPitch(void* h, float v);
+void orc_binauraliser_setRoll(void* h, float v);
+void orc_binauraliser_setRPYflag(void* h, int s);
+void orc_binauraliser_setInterpMode(void* h, int m);
+void orc_binauraliser_setSourceGain(void* h, int i, float g);
+int  orc_binauraliser_getNDirs(void* h);
+int  orc_binauraliser_getNTriangles(void* h);
+const float* orc_binauraliser_getITDs(void* h);
+const float* orc_binauraliser_getWeights(void* h);
+const orc_cpx* orc_binauraliser_getHRTFfb(void* h);
+const orc_cpx* orc_binauraliser_getHRTFinterp(void* h);
+
 #ifdef __cplusplus
 }
 #endif

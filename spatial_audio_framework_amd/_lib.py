@@ -149,5 +149,44 @@ def load():
     sig("saf_matrixConv_apply", None, vp, fp, fp)
     sig("saf_hip_matrixConv_setMaxBlocksPerCall", None, ci)
     sig("saf_hip_matrixConv_apply_dev", None, vp, vp, cll, cll, vp, cll, cll, ci)
+    # HRIR processing + binauraliser
+    sig("estimateITDs", None, fp, ci, ci, ci, fp)
+    sig("HRIRs2HRTFs_afSTFT", None, fp, ci, ci, ci, ci, ci, vp)
+    sig("diffuseFieldEqualiseHRTFs", None, ci, fp, fp, ci, fp, ci, ci, vp)
+    sig("getVoronoiWeights", None, fp, ci, ci, fp)
+    sig("saf_hip_setDefaultHRIRs", None, fp, fp, ci, ci, ci)
+    sig("saf_hip_binauraliser_setFrameSize", None, ci)
+    sig("saf_hip_binauraliser_setMaxNumSources", None, ci)
+    sig("binauraliser_create", None, C.POINTER(vp))
+    sig("binauraliser_destroy", None, C.POINTER(vp))
+    sig("binauraliser_init", None, vp, ci)
+    sig("binauraliser_initCodec", None, vp)
+    sig("binauraliser_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("binauraliser_refreshSettings", None, vp)
+    for n in ("setNumSources", "setUseDefaultHRIRsflag", "setEnableHRIRsDiffuseEQ", "setInputConfigPreset", "setEnableRotation", "setFlipYaw",
+              "setFlipPitch", "setFlipRoll", "setRPYflag", "setInterpMode", "setSourceSolo"):
+        sig("binauraliser_" + n, None, vp, ci)
+    for n in ("setSourceAzi_deg", "setSourceElev_deg", "setSourceGain"):
+        sig("binauraliser_" + n, None, vp, ci, cf)
+    for n in ("setYaw", "setPitch", "setRoll"):
+        sig("binauraliser_" + n, None, vp, cf)
+    sig("binauraliser_setSofaFilePath", None, vp, C.c_char_p)
+    sig("binauraliser_setUnSolo", None, vp)
+    for n in ("getFrameSize", "getMaxNumSources", "getNumEars", "getProcessingDelay"):
+        sig("binauraliser_" + n, ci)
+    for n in ("getCodecStatus", "getNumSources", "getNDirs", "getNTriangles", "getHRIRlength", "getHRIRsamplerate", "getUseDefaultHRIRsflag",
+              "getEnableHRIRsDiffuseEQ", "getDAWsamplerate", "getEnableRotation", "getFlipYaw", "getFlipPitch", "getFlipRoll", "getRPYflag", "getInterpMode"):
+        sig("binauraliser_" + n, ci, vp)
+    for n in ("getProgressBar0_1", "getYaw", "getPitch", "getRoll"):
+        sig("binauraliser_" + n, cf, vp)
+    for n in ("getSourceAzi_deg", "getSourceElev_deg", "getHRIRAzi_deg", "getHRIRElev_deg"):
+        sig("binauraliser_" + n, cf, vp, ci)
+    sig("binauraliser_getProgressBarText", None, vp, C.c_char_p)
+    sig("binauraliser_getSofaFilePath", C.c_char_p, vp)
+    sig("saf_hip_binauraliser_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci)
+    sig("saf_hip_binauraliser_getITDs", None, vp, fp)
+    sig("saf_hip_binauraliser_getWeights", None, vp, fp)
+    sig("saf_hip_binauraliser_getHRTFfb", None, vp, vp)
+    sig("saf_hip_binauraliser_getHRTFinterp", None, vp, vp)
     _lib = L
     return L

@@ -336,3 +336,83 @@ class MatrixConv:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.saf_matrixConv_destroy(C.byref(self.h))
+
+
+# ---------------------------------------------------------------- HRIR processing / binauraliser
+def estimateITDs(hrirs, fs):
+    hrirs = np.ascontiguousarray(hrirs, np.float32)
+    N, _, L = hrirs.shape
+    out = np.zeros(N, np.float32)
+    load().estimateITDs(_f(hrirs), N, L, fs, _f(out))
+    return out
+
+
+def getVoronoiWeights(dirs_deg):
+    d = np.ascontiguousarray(dirs_deg, np.float32)
+    out = np.zeros(d.shape[0], np.float32)
+    load().getVoronoiWeights(_f(d), d.shape[0], 0, _f(out))
+    return out
+
+
+def diffuseFieldEqualiseHRTFs(hrtfs, weights=None):
+    h = np.ascontiguousarray(hrtfs, np.complex64).copy()
+    nB, _, N = h.shape
+    w = None if weights is None else np.ascontiguousarray(weights, np.float32)
+    load().diffuseFieldEqualiseHRTFs(N, None, None, nB, _f(w) if w is not None else None, 1, 0, h.ctypes.data_as(vp))
+    return h
+
+
+def setDefaultHRIRs(hrirs, dirs_deg, fs):
+    hrirs = np.ascontiguousarray(hrirs, np.float32); d = np.ascontiguousarray(dirs_deg, np.float32)
+    load().saf_hip_setDefaultHRIRs(_f(hrirs), _f(d), hrirs.shape[0], hrirs.shape[2], fs)
+
+
+class Binauraliser:
+    """examples/include/binauraliser.h.  `frameSize` plays the role of -DBINAURALISER_FRAME_SIZE, `maxSources` of MAX_NUM_INPUTS."""
+
+    def __init__(self, frameSize=128, maxSources=64):
+        self.L = load()
+        self.L.saf_hip_binauraliser_setFrameSize(frameSize)
+        self.L.saf_hip_binauraliser_setMaxNumSources(maxSources)
+        self.h = vp()
+        self.F = frameSize
+        self.maxSources = maxSources
+        self.L.binauraliser_create(C.byref(self.h))
+        self.L.saf_hip_binauraliser_setMaxNumSources(64)
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "binauraliser_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def setHRIRs(self, hrirs, dirs_deg, fs):
+        setDefaultHRIRs(hrirs, dirs_deg, fs)
+        self.L.binauraliser_refreshSettings(self.h)
+
+    def process(self, x, nOut=2, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.binauraliser_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def process_dev(self, d_in, in_strides, nIn, d_out, out_strides, nFrames):
+        """strides = (frame, ch) in floats."""
+        self.L.saf_hip_binauraliser_process_dev(self.h, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nFrames)
+
+    def itds(self):
+        out = np.zeros(self.L.binauraliser_getNDirs(self.h), np.float32); self.L.saf_hip_binauraliser_getITDs(self.h, _f(out)); return out
+
+    def weights(self):
+        out = np.zeros(self.L.binauraliser_getNDirs(self.h), np.float32); self.L.saf_hip_binauraliser_getWeights(self.h, _f(out)); return out
+
+    def hrtf_fb(self):
+        out = np.zeros((133, 2, self.L.binauraliser_getNDirs(self.h)), np.complex64)
+        self.L.saf_hip_binauraliser_getHRTFfb(self.h, out.ctypes.data_as(vp)); return out
+
+    def hrtf_interp(self, nSrc):
+        out = np.zeros((nSrc, 133, 2), np.complex64)
+        self.L.saf_hip_binauraliser_getHRTFinterp(self.h, out.ctypes.data_as(vp)); return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.binauraliser_destroy(C.byref(self.h))

@@ -1,0 +1,125 @@
+/*
+ * binaural_kernels.hip — the per-block kernels of the binauraliser (examples/src/binauraliser) for gfx950.
+ *
+ *   hrtf_interp_kernel   binauraliser_interpHRTFs (binauraliser_internal.c:46-123): nearest point of the 2 x 5 degree
+ *                        VBAP grid over the HRIR directions -> 3 gains + 3 HRIR indices -> either the complex
+ *                        triangular interpolation (INTERP_TRI) or magnitude + ITD interpolation with the interaural
+ *                        phase re-introduced below 1.5 kHz (INTERP_TRI_PS).  One workgroup per source that moved.
+ *   binaural_mac_kernel  the band MAC of binauraliser_process (binauraliser.c:252-268): per band a [2 x nSrc] x
+ *                        [nSrc x T] complex product.  Spectra rows [src][hop] are read exactly once; the source sum is
+ *                        split over the thread groups of a workgroup and folded through LDS.
+ */
+#include "saf_hip_common.h"
+
+namespace saf {
+
+__device__ __forceinline__ float dev_matlab_fmodf(float x, float y) { const float t = fmodf(x, y); return t >= 0 ? t : t + y; }
+
+struct InterpArgs { HrtfInterpLaunch l; };
+
+__global__ __launch_bounds__(192) void hrtf_interp_kernel(InterpArgs a)
+{
+    const HrtfInterpLaunch& l = a.l;
+    const int src = blockIdx.x, band = threadIdx.x;
+    if (!l.recalc[src] || band >= SAF_NBANDS) return;
+    const float azi = l.srcDirs[src * 2], elev = l.srcDirs[src * 2 + 1];
+    const float aziRes = (float)l.aziRes, elevRes = (float)l.elevRes;
+    const int N_azi = (int)(360.0f / aziRes + 0.5f) + 1;
+    const int aziIndex = (int)(dev_matlab_fmodf(azi + 180.0f, 360.0f) / aziRes + 0.5f);
+    const int elevIndex = (int)((elev + 90.0f) / elevRes + 0.5f);
+    const int idx3d = elevIndex * N_azi + aziIndex;
+    float w[3]; int id[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { w[i] = l.gtComp[idx3d * 3 + i]; id[i] = l.gtIdx[idx3d * 3 + i]; }
+    float2* out = l.hrtf_interp + ((long long)src * SAF_NBANDS + band) * 2;
+    if (l.mode == 1) {                                                  /* INTERP_TRI (binauraliser.h:58-61) */
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float2* h = l.hrtf_fb + ((long long)band * 2 + e) * l.N;
+            float re = 0.0f, im = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { const float2 v = h[id[i]]; re = fmaf(v.x, w[i], re); im = fmaf(v.y, w[i], im); }
+            out[e] = make_float2(re, im);
+        }
+    } else {                                                            /* INTERP_TRI_PS */
+        float itd = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) itd = fmaf(w[i], l.itds[id[i]], itd);
+        float mag[2] = { 0.0f, 0.0f };
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int i = 0; i < 3; i++) mag[e] = fmaf(w[i], l.hrtf_mag[((long long)band * 2 + e) * l.N + id[i]], mag[e]);
+        const float f = l.freq[band];
+        const float ipd = f < 1.5e3f ? (dev_matlab_fmodf(2.0f * SAF_PI * f * itd + SAF_PI, 2.0f * SAF_PI) - SAF_PI) / 2.0f : 0.0f;
+        float s, c;
+        sincosf(ipd, &s, &c);
+        out[0] = make_float2(c * mag[0], s * mag[0]);
+        out[1] = make_float2(c * mag[1], -s * mag[1]);
+    }
+}
+
+void launch_hrtf_interp(const HrtfInterpLaunch& l)
+{
+    if (l.nSrc <= 0) return;
+    InterpArgs a; a.l = l;
+    KernelTimer kt("hrtf_interp");
+    hipLaunchKernelGGL(hrtf_interp_kernel, dim3(l.nSrc), dim3(192), 0, stream(), a);
+    HIP_CHECK(hipGetLastError());
+}
+
+struct MacArgs2 { BinMacLaunch l; int TT, logTT; };
+
+/* grid (ceil(H / TT), 133); 256 threads = TT hops x (256 / TT) source groups */
+__global__ __launch_bounds__(256) void binaural_mac_kernel(MacArgs2 a)
+{
+    __shared__ float2 s_red[256][2];
+    const BinMacLaunch& l = a.l;
+    const int band = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int t = tid & (a.TT - 1), sg = tid >> a.logTT, nG = 256 >> a.logTT;
+    const int hop = blockIdx.x * a.TT + t;
+    float2 accL = make_float2(0.f, 0.f), accR = make_float2(0.f, 0.f);
+    if (hop < l.H) {
+        const float2* X = l.X + (long long)band * l.x_band + hop;
+        for (int src = sg; src < l.nSrc; src += nG) {
+            const float2 x = X[(long long)src * l.x_ch];
+            const float2 hl = l.h[((long long)src * SAF_NBANDS + band) * 2], hr = l.h[((long long)src * SAF_NBANDS + band) * 2 + 1];
+            accL.x = fmaf(hl.x, x.x, accL.x); accL.x = fmaf(-hl.y, x.y, accL.x);
+            accL.y = fmaf(hl.x, x.y, accL.y); accL.y = fmaf(hl.y, x.x, accL.y);
+            accR.x = fmaf(hr.x, x.x, accR.x); accR.x = fmaf(-hr.y, x.y, accR.x);
+            accR.y = fmaf(hr.x, x.y, accR.y); accR.y = fmaf(hr.y, x.x, accR.y);
+        }
+    }
+    s_red[tid][0] = accL; s_red[tid][1] = accR;
+    __syncthreads();
+    for (int stride = nG >> 1; stride >= 1; stride >>= 1) {
+        if (sg < stride) {
+            const int o = tid + (stride << a.logTT);
+#pragma unroll
+            for (int e = 0; e < 2; e++) { s_red[tid][e].x += s_red[o][e].x; s_red[tid][e].y += s_red[o][e].y; }
+        }
+        __syncthreads();
+    }
+    if (sg == 0 && hop < l.H) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float2 v = s_red[tid][e];
+            l.Y[(long long)band * l.y_band + (long long)e * l.y_ch + hop] = make_float2(v.x * l.scale, v.y * l.scale);     /* cblas_sscal 1/sqrt(nSources) */
+        }
+    }
+}
+
+void launch_binaural_mac(const BinMacLaunch& l)
+{
+    if (l.H <= 0 || l.nSrc <= 0) return;
+    MacArgs2 a; a.l = l;
+    int TT = 1, lg = 0;
+    while (TT < l.H && TT < 64) { TT <<= 1; lg++; }
+    a.TT = TT; a.logTT = lg;
+    KernelTimer kt("binaural_mac");
+    hipLaunchKernelGGL(binaural_mac_kernel, dim3((l.H + TT - 1) / TT, SAF_NBANDS), dim3(256), 0, stream(), a);
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace saf

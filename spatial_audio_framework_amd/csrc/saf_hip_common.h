@@ -181,4 +181,25 @@ struct PconvApply {         /* MAC over (partition, input) + one inverse FFT per
 void pconv_launch_apply(const PconvApply& p);
 void pconv_twiddles(int N, DevBuf<float2>& tw);
 
+/* ---- binaural rendering kernels (binaural_kernels.hip) ---- */
+struct HrtfInterpLaunch {       /* binauraliser_interpHRTFs (binauraliser_internal.c:46-123) for every flagged source */
+    const float* srcDirs;       /* [nSrc][2] azimuth, elevation in degrees (after any head rotation) */
+    const int* recalc;          /* [nSrc] */
+    const float* gtComp; const int* gtIdx;      /* compressed VBAP table over the HRIR grid: [nTable][3] gains / indices */
+    const float2* hrtf_fb;      /* [133][2][N] */
+    const float* hrtf_mag;      /* [133][2][N] */
+    const float* itds;          /* [N] */
+    const float* freq;          /* [133] */
+    float2* hrtf_interp;        /* [nSrc][133][2] */
+    int nSrc, N, mode, aziRes, elevRes;
+};
+void launch_hrtf_interp(const HrtfInterpLaunch& l);
+struct BinMacLaunch {           /* out[band][ear][t] = scale * sum_src h[src][band][ear] * X[band][src][t]  (binauraliser.c:252-268) */
+    const float2* X; long long x_band, x_ch;
+    const float2* h;
+    float2* Y; long long y_band, y_ch;
+    int nSrc, H; float scale;
+};
+void launch_binaural_mac(const BinMacLaunch& l);
+
 }  // namespace saf

@@ -43,3 +43,36 @@ def canon_faces(F):
     """Canonical form of a face list: each triangle's vertices sorted, rows sorted."""
     F = np.sort(np.asarray(F, np.int64), axis=1)
     return F[np.lexsort(F.T[::-1])]
+
+
+def fibonacci_dirs_deg(N):
+    """N roughly uniform directions [azimuth 0..360, elevation] in degrees (Fibonacci sphere)."""
+    i = np.arange(N) + 0.5
+    el = np.degrees(np.arcsin(1.0 - 2.0 * i / N))
+    az = np.mod(np.degrees(np.pi * (1.0 + 5.0 ** 0.5) * i), 360.0)
+    return np.stack([az, el], 1).astype(np.float32)
+
+
+def synth_hrirs(N=836, L=256, fs=48000, seed=7):
+    """Synthetic stand-in for the reference's default HRIR set (absent from the checkout): same shapes
+    ([N][2][L] at 48 kHz, 836 directions) with a spherical-head delay/level model and a direction-dependent decaying
+    tail, deterministic.  Returns (hrirs float32 [N][2][L], dirs_deg float32 [N][2] with azimuth in 0..360)."""
+    rng = np.random.default_rng(seed)
+    dirs = fibonacci_dirs_deg(N)
+    az, el = np.radians(dirs[:, 0]), np.radians(dirs[:, 1])
+    lat = np.sin(az) * np.cos(el)                     # +1: source at the left ear side (az = +90)
+    h = np.zeros((N, 2, L), np.float64)
+    n = np.arange(L)
+    for ear, sgn in ((0, 1.0), (1, -1.0)):
+        delay = 40.0 - sgn * lat * 0.00035 * fs                                  # samples; near ear earlier
+        gain = 10.0 ** (sgn * lat * 6.0 / 20.0)
+        for d in range(N):
+            k = int(np.floor(delay[d])); fr = delay[d] - k
+            h[d, ear, k] += (1 - fr) * gain[d]; h[d, ear, k + 1] += fr * gain[d]
+            tail = rng.normal(size=L) * np.exp(-(n - k) / (12.0 + 6.0 * (1 + sgn * lat[d]))) * (n > k + 1) * 0.15 * gain[d]
+            h[d, ear] += tail
+    # gentle low-pass (gain 0.4 at Nyquist: measured HRIRs keep energy up there; a null would be blown up by the
+    # diffuse-field equalisation together with its rounding noise)
+    ker = np.array([0.15, 0.7, 0.15])
+    h = np.apply_along_axis(lambda v: np.convolve(v, ker, mode="same"), 2, h)
+    return h.astype(np.float32), dirs
