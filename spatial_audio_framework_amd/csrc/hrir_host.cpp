@@ -14,7 +14,8 @@
 #include <algorithm>
 
 /* The spherical excess of a Voronoi cell is a difference of numbers ~1e3 times larger than the cell area, so its float32
- * value depends on every rounding: keep multiply and add separate, like the oracle build (-ffp-contract=off). */
+ * value depends on every rounding: keep multiply and add separate (what a plain C build of the reference does, and
+ * what the parity tests assume). */
 #pragma clang fp contract(off)
 
 namespace saf {
