@@ -375,6 +375,64 @@ SAF_API void saf_hip_binauraliser_getWeights(void* const hBin, float* weights);
 SAF_API void saf_hip_binauraliser_getHRTFfb(void* const hBin, float_complex* hrtf_fb);        /* [133][2][N] */
 SAF_API void saf_hip_binauraliser_getHRTFinterp(void* const hBin, float_complex* hrtf_interp);/* [nSources][133][2] */
 
+/* ========================================================================== */
+/*      powermap (examples/include/powermap.h:87-371), PWD mode               */
+/* ========================================================================== */
+typedef enum { PM_MODE_PWD = 1, PM_MODE_MVDR, PM_MODE_CROPAC_LCMV, PM_MODE_MUSIC, PM_MODE_MUSIC_LOG, PM_MODE_MINNORM, PM_MODE_MINNORM_LOG } POWERMAP_MODES; /* powermap.h:58-74 */
+/** The reference fixes the frame size at compile time (-DPOWERMAP_FRAME_SIZE, default 1024); here it is a process-wide
+ *  setting read by powermap_create (multiple of 128, at most 2048). */
+SAF_API void saf_hip_powermap_setFrameSize(int frameSize);
+SAF_API void powermap_create(void** const phPm);                                  /* powermap.h:87 */
+SAF_API void powermap_destroy(void** const phPm);                                 /* powermap.h:94 */
+SAF_API void powermap_init(void* const hPm, float samplerate);                    /* powermap.h:104 */
+SAF_API void powermap_initCodec(void* const hPm);                                 /* powermap.h:122 */
+SAF_API void powermap_analysis(void* const hPm, const float* const* inputs, int nInputs, int nSamples, int isPlaying); /* powermap.h:134 */
+SAF_API void powermap_refreshSettings(void* const hPm);                           /* powermap.h:149 */
+SAF_API void powermap_setPowermapMode(void* const hPm, int newMode);              /* powermap.h:152 */
+SAF_API void powermap_setMasterOrder(void* const hPm, int newValue);              /* powermap.h:155 */
+SAF_API void powermap_setAnaOrder(void* const hPm, int newValue, int bandIdx);    /* powermap.h:158 */
+SAF_API void powermap_setAnaOrderAllBands(void* const hPm, int newValue);         /* powermap.h:161 */
+SAF_API void powermap_setPowermapEQ(void* const hPm, float newValue, int bandIdx);/* powermap.h:167 */
+SAF_API void powermap_setPowermapEQAllBands(void* const hPm, float newValue);     /* powermap.h:170 */
+SAF_API void powermap_setCovAvgCoeff(void* const hPm, float newAvg);              /* powermap.h:173 */
+SAF_API void powermap_setChOrder(void* const hPm, int newOrder);                  /* powermap.h:179 */
+SAF_API void powermap_setNormType(void* const hPm, int newType);                  /* powermap.h:185 */
+SAF_API void powermap_setSourcePreset(void* const hPm, int newPresetID);          /* powermap.h:191 */
+SAF_API void powermap_setNumSources(void* const hPm, int newValue);               /* powermap.h:194 */
+SAF_API void powermap_setDispFOV(void* const hPm, int newOption);                 /* powermap.h:200 */
+SAF_API void powermap_setAspectRatio(void* const hPm, int newOption);             /* powermap.h:206 */
+SAF_API void powermap_setPowermapAvgCoeff(void* const hPm, float newValue);       /* powermap.h:209 */
+SAF_API void powermap_requestPmapUpdate(void* const hPm);                         /* powermap.h:215 */
+SAF_API int  powermap_getFrameSize(void);                                         /* powermap.h:226 */
+SAF_API CODEC_STATUS powermap_getCodecStatus(void* const hPm);                    /* powermap.h:229 */
+SAF_API float powermap_getProgressBar0_1(void* const hPm);                        /* powermap.h:236 */
+SAF_API void powermap_getProgressBarText(void* const hPm, char* text);            /* powermap.h:243 */
+SAF_API int  powermap_getMasterOrder(void* const hPm);                            /* powermap.h:248 */
+SAF_API int  powermap_getPowermapMode(void* const hPm);                           /* powermap.h:254 */
+SAF_API int  powermap_getSamplingRate(void* const hPm);                           /* powermap.h:257 */
+SAF_API float powermap_getCovAvgCoeff(void* const hPm);                           /* powermap.h:260 */
+SAF_API int  powermap_getNumberOfBands(void);                                     /* powermap.h:263 */
+SAF_API int  powermap_getNSHrequired(void* const hPm);                            /* powermap.h:269 */
+SAF_API float powermap_getPowermapEQ(void* const hPm, int bandIdx);               /* powermap.h:275 */
+SAF_API float powermap_getPowermapEQAllBands(void* const hPm);                    /* powermap.h:280 */
+SAF_API void powermap_getPowermapEQHandle(void* const hPm, float** pX_vector, float** pY_values, int* pNpoints); /* powermap.h:290 */
+SAF_API int  powermap_getAnaOrder(void* const hPm, int bandIdx);                  /* powermap.h:296 */
+SAF_API int  powermap_getAnaOrderAllBands(void* const hPm);                       /* powermap.h:299 */
+SAF_API void powermap_getAnaOrderHandle(void* const hPm, float** pX_vector, int** pY_values, int* pNpoints);     /* powermap.h:309 */
+SAF_API int  powermap_getChOrder(void* const hPm);                                /* powermap.h:319 */
+SAF_API int  powermap_getNormType(void* const hPm);                               /* powermap.h:326 */
+SAF_API int  powermap_getNumSources(void* const hPm);                             /* powermap.h:329 */
+SAF_API int  powermap_getDispFOV(void* const hPm);                                /* powermap.h:335 */
+SAF_API int  powermap_getAspectRatio(void* const hPm);                            /* powermap.h:341 */
+SAF_API float powermap_getPowermapAvgCoeff(void* const hPm);                      /* powermap.h:344 */
+SAF_API int  powermap_getPmap(void* const hPm, float** grid_dirs, float** pmap, int* nDirs, int* pmapWidth, int* hfov, int* aspectRatio); /* powermap.h:359 */
+SAF_API int  powermap_getProcessingDelay(void);                                   /* powermap.h:371 */
+/** Device-pointer entry: nFrames whole frames (the input FIFO must be empty), in[frame*in_frame_stride + ch*in_ch_stride + n]. */
+SAF_API void saf_hip_powermap_analysis_dev(void* const hPm, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs, int nFrames);
+/** Read-back for parity checks: Cx as [133][nSH][nSH]; the smoothed map on the 812-point scanning grid (returns its length). */
+SAF_API void saf_hip_powermap_getCx(void* const hPm, float_complex* Cx);
+SAF_API int  saf_hip_powermap_getRawPmap(void* const hPm, float* pmap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ vp = C.c_void_p
 
 def build(force=False):
     so = HERE / "libsaf_oracle.so"
-    srcs = [HERE / n for n in ("orc_core.c", "orc_sh.c", "orc_examples.c", "orc_binaural.c", "saf_oracle.h")]
+    srcs = [HERE / n for n in ("orc_core.c", "orc_sh.c", "orc_examples.c", "orc_binaural.c", "orc_powermap.c", "saf_oracle.h")]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
         subprocess.check_call(["make", "-s", "-C", str(HERE)])
     if Path("/root/reference/framework/resources/kissFFT/kiss_fftr.c").exists():
@@ -426,3 +426,42 @@ class Binauraliser:
     def __del__(self):
         if self.h:
             lib().orc_binauraliser_destroy(C.byref(self.h))
+
+
+# ------------------------------------------------------------------ powermap (PWD)
+class Powermap:
+    def __init__(self, frameSize=1024):
+        self.h = vp()
+        self.F = frameSize
+        L = lib()
+        L.orc_powermap_create(C.byref(self.h), frameSize)
+        L.orc_powermap_getCx.restype = vp
+        L.orc_powermap_getRawPmap.restype = c_f
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_powermap_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def analysis(self, x, isPlaying=1):
+        x = np.ascontiguousarray(x, np.float32)
+        lib().orc_powermap_analysis(self.h, _chan_ptrs(x), x.shape[0], x.shape[1], isPlaying)
+
+    def Cx(self, nSH):
+        p = C.cast(lib().orc_powermap_getCx(self.h), C.POINTER(C.c_float))
+        a = np.ctypeslib.as_array(p, shape=(133, 64 * 64, 2)).copy().view(np.complex64)[..., 0]
+        return a[:, :nSH * nSH].reshape(133, nSH, nSH)
+
+    def rawPmap(self):
+        n = lib().orc_powermap_getGridNDirs(self.h)
+        return np.ctypeslib.as_array(lib().orc_powermap_getRawPmap(self.h), shape=(n,)).copy()
+
+    def getPmap(self):
+        gd, pm, n = c_f(), c_f(), C.c_int()
+        ready = lib().orc_powermap_getPmap(self.h, C.byref(gd), C.byref(pm), C.byref(n))
+        if not ready:
+            return None
+        return np.ctypeslib.as_array(pm, shape=(n.value,)).copy()
+
+    def __del__(self):
+        if self.h:
+            lib().orc_powermap_destroy(C.byref(self.h))

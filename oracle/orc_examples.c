@@ -408,7 +408,8 @@ void orc_ambi_enc_process(void* h, const float* const* inputs, float* const* out
 }
 /* setters (ambi_enc.c:205-330) */
 void orc_ambi_enc_setOutputOrder(void* h, int o) { orc_ambi_enc* p = (orc_ambi_enc*)h; if (o != p->order) { p->order = o; for (int i = 0; i < MAX_CH; i++) p->recalc_SH_FLAG[i] = 1;
-    if (p->order != 1 && p->chOrdering == 2) p->chOrdering = 1; if (p->order != 1 && p->norm == 3) p->norm = 2; } }
+    if (p->order != 1 && p->chOrdering == 2) p->chOrdering = 1;
+    if (p->order != 1 && p->norm == 3) p->norm = 2; } }
 void orc_ambi_enc_setNumSources(void* h, int n) { orc_ambi_enc* p = (orc_ambi_enc*)h; p->nSources = CLAMPI(n, 1, MAX_CH); for (int i = 0; i < MAX_CH; i++) p->recalc_SH_FLAG[i] = 1; }
 void orc_ambi_enc_setSourceAzi_deg(void* h, int idx, float a) { orc_ambi_enc* p = (orc_ambi_enc*)h; if (a > 180.0f) a = -360.0f + a; a = a < -180.0f ? -180.0f : (a > 180.0f ? 180.0f : a); p->recalc_SH_FLAG[idx] = 1; p->src_dirs_deg[idx][0] = a; }
 void orc_ambi_enc_setSourceElev_deg(void* h, int idx, float e) { orc_ambi_enc* p = (orc_ambi_enc*)h; e = e < -90.0f ? -90.0f : (e > 90.0f ? 90.0f : e); p->recalc_SH_FLAG[idx] = 1; p->src_dirs_deg[idx][1] = e; }

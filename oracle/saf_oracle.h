@@ -158,6 +158,27 @@ const float* orc_binauraliser_getWeights(void* h);
 const orc_cpx* orc_binauraliser_getHRTFfb(void* h);
 const orc_cpx* orc_binauraliser_getHRTFinterp(void* h);
 
+/* ---- powermap, PWD mode (examples/src/powermap) ---- */
+void orc_powermap_create(void** ph, int frameSize);
+void orc_powermap_destroy(void** ph);
+void orc_powermap_init(void* h, float sampleRate);
+void orc_powermap_initCodec(void* h);
+void orc_powermap_analysis(void* h, const float* const* inputs, int nInputs, int nSamples, int isPlaying);
+void orc_powermap_setPowermapMode(void* h, int m);
+void orc_powermap_setMasterOrder(void* h, int o);
+void orc_powermap_setCovAvgCoeff(void* h, float a);
+void orc_powermap_setAnaOrder(void* h, int o, int band);
+void orc_powermap_setAnaOrderAllBands(void* h, int o);
+void orc_powermap_setPowermapEQ(void* h, float v, int band);
+void orc_powermap_setChOrder(void* h, int v);
+void orc_powermap_setNormType(void* h, int v);
+void orc_powermap_setPowermapAvgCoeff(void* h, float v);
+void orc_powermap_requestPmapUpdate(void* h);
+int  orc_powermap_getPmap(void* h, const float** grid_dirs, const float** pmap, int* nDirs);
+const orc_cpx* orc_powermap_getCx(void* h);          /* [133][64*64], row stride nSH of the master order */
+const float* orc_powermap_getRawPmap(void* h);       /* [grid_nDirs] after temporal smoothing */
+int  orc_powermap_getGridNDirs(void* h);
+
 #ifdef __cplusplus
 }
 #endif

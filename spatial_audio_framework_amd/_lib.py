@@ -188,5 +188,36 @@ def load():
     sig("saf_hip_binauraliser_getWeights", None, vp, fp)
     sig("saf_hip_binauraliser_getHRTFfb", None, vp, vp)
     sig("saf_hip_binauraliser_getHRTFinterp", None, vp, vp)
+    # powermap
+    sig("saf_hip_powermap_setFrameSize", None, ci)
+    sig("powermap_create", None, C.POINTER(vp))
+    sig("powermap_destroy", None, C.POINTER(vp))
+    sig("powermap_init", None, vp, cf)
+    sig("powermap_initCodec", None, vp)
+    sig("powermap_analysis", None, vp, C.POINTER(fp), ci, ci, ci)
+    sig("powermap_refreshSettings", None, vp)
+    sig("powermap_requestPmapUpdate", None, vp)
+    for n in ("setPowermapMode", "setMasterOrder", "setAnaOrderAllBands", "setChOrder", "setNormType", "setSourcePreset", "setNumSources", "setDispFOV", "setAspectRatio"):
+        sig("powermap_" + n, None, vp, ci)
+    sig("powermap_setAnaOrder", None, vp, ci, ci)
+    sig("powermap_setPowermapEQ", None, vp, cf, ci)
+    for n in ("setPowermapEQAllBands", "setCovAvgCoeff", "setPowermapAvgCoeff"):
+        sig("powermap_" + n, None, vp, cf)
+    for n in ("getFrameSize", "getNumberOfBands", "getProcessingDelay"):
+        sig("powermap_" + n, ci)
+    for n in ("getCodecStatus", "getMasterOrder", "getPowermapMode", "getSamplingRate", "getNSHrequired", "getAnaOrderAllBands", "getChOrder", "getNormType",
+              "getNumSources", "getDispFOV", "getAspectRatio"):
+        sig("powermap_" + n, ci, vp)
+    for n in ("getProgressBar0_1", "getCovAvgCoeff", "getPowermapEQAllBands", "getPowermapAvgCoeff"):
+        sig("powermap_" + n, cf, vp)
+    sig("powermap_getPowermapEQ", cf, vp, ci)
+    sig("powermap_getAnaOrder", ci, vp, ci)
+    sig("powermap_getProgressBarText", None, vp, C.c_char_p)
+    sig("powermap_getPowermapEQHandle", None, vp, C.POINTER(fp), C.POINTER(fp), ip)
+    sig("powermap_getAnaOrderHandle", None, vp, C.POINTER(fp), C.POINTER(ip), ip)
+    sig("powermap_getPmap", ci, vp, C.POINTER(fp), C.POINTER(fp), ip, ip, ip, ip)
+    sig("saf_hip_powermap_analysis_dev", None, vp, vp, cll, cll, ci, ci)
+    sig("saf_hip_powermap_getCx", None, vp, vp)
+    sig("saf_hip_powermap_getRawPmap", ci, vp, fp)
     _lib = L
     return L

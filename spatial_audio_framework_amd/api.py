@@ -416,3 +416,46 @@ class Binauraliser:
     def __del__(self):
         if getattr(self, "h", None):
             self.L.binauraliser_destroy(C.byref(self.h))
+
+
+# ---------------------------------------------------------------- powermap (PWD)
+class Powermap:
+    """examples/include/powermap.h.  `frameSize` plays the role of -DPOWERMAP_FRAME_SIZE."""
+
+    def __init__(self, frameSize=1024):
+        self.L = load()
+        self.L.saf_hip_powermap_setFrameSize(frameSize)
+        self.h = vp()
+        self.F = frameSize
+        self.L.powermap_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "powermap_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def analysis(self, x, isPlaying=1):
+        x = np.ascontiguousarray(x, np.float32)
+        self.L.powermap_analysis(self.h, _rows(x), x.shape[0], x.shape[1], isPlaying)
+
+    def analysis_dev(self, d_in, strides, nIn, nFrames):
+        """strides = (frame, ch) in floats."""
+        self.L.saf_hip_powermap_analysis_dev(self.h, vp(d_in), *strides, nIn, nFrames)
+
+    def Cx(self, nSH):
+        out = np.zeros((133, nSH, nSH), np.complex64)
+        self.L.saf_hip_powermap_getCx(self.h, out.ctypes.data_as(vp)); return out
+
+    def rawPmap(self):
+        out = np.zeros(4096, np.float32)
+        n = self.L.saf_hip_powermap_getRawPmap(self.h, _f(out)); return out[:n].copy()
+
+    def getPmap(self):
+        gd, pm = fp(), fp()
+        n, w, hf, ar = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        if not self.L.powermap_getPmap(self.h, C.byref(gd), C.byref(pm), C.byref(n), C.byref(w), C.byref(hf), C.byref(ar)):
+            return None
+        return np.ctypeslib.as_array(pm, shape=(n.value,)).copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.powermap_destroy(C.byref(self.h))

@@ -202,4 +202,20 @@ struct BinMacLaunch {           /* out[band][ear][t] = scale * sum_src h[src][ba
 };
 void launch_binaural_mac(const BinMacLaunch& l);
 
+/* ---- powermap kernels (powermap_kernels.hip) ---- */
+struct CovLaunch {              /* Cx[b] <- a Cx[b] + (1-a) X_f X_f^H for consecutive frames f (powermap.c:258-267) */
+    const float2* X; long long x_band, x_ch;     /* spectra [band][ch][hop] */
+    float2* Cx;                 /* [133][64][64] */
+    int nSH, T, nFrames; float alpha;
+};
+void launch_cov_update(const CovLaunch& l);
+struct PwdLaunch {              /* grouped covariance + PWD map + temporal smoothing (powermap.c:276-347, saf_sh.c:1544-1584) */
+    const float2* Cx; const float* bandScale /* [133] 1e3*EQ */; const int* bandNSH /* [133] */;
+    float* Cg;                  /* scratch [64][64] (real part) */
+    const float* Ygrid;         /* [nM][G] scaled 1/nM */
+    float* pmap; float* prev_pmap;
+    int nM, G; float avg;
+};
+void launch_pwd_map(const PwdLaunch& l);
+
 }  // namespace saf

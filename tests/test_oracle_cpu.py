@@ -370,3 +370,36 @@ def test_binauraliser_oracle_chain_sanity(orc):
     y2 = np.concatenate([b.process(x[:, i * 128:(i + 1) * 128]) for i in range(24)], 1)
     e2 = (y2[:, 128 * 14:] ** 2).sum(1)
     assert 0.5 < e2[0] / e2[1] < 2.0                       # now (nearly) frontal: ears balanced
+
+
+def test_powermap_oracle_closed_forms(orc):
+    """powermap (PWD) has no reference test.  Closed forms: with covAvgCoeff = 0 the band covariance is X X^H
+    of that frame's spectra; the PWD map is y^T Re(C) y on the 812-point grid and peaks at the plane-wave direction."""
+    order, F = 3, 1024
+    nSH = (order + 1) ** 2
+    pm = orc.Powermap(F); pm.setMasterOrder(order); pm.setPowermapMode(1); pm.init(48000.0); pm.initCodec()
+    pm.setAnaOrderAllBands(order); pm.setNormType(1); pm.setPowermapAvgCoeff(0.0)
+    s = frames(1, 1, F * 3)
+    x = (orc.getRSH(order, np.array([[60.0, 20.0]], np.float32)) @ s).astype(np.float32)
+    st = orc.AfSTFT(nSH, 0)
+    for f in range(3):
+        if f == 2:
+            pm.requestPmapUpdate()
+        blk = x[:, f * F:(f + 1) * F]
+        pm.analysis(blk)
+        X = st.forward(blk).astype(np.complex128)
+    C = pm.Cx(nSH)
+    ref = np.einsum("bit,bjt->bij", X, X.conj())
+    assert relrms(C, ref) < 2e-6
+    grid = orc.table("geosphere_ico_9_0_dirs_deg")
+    Y = orc.getRSH(order, grid).astype(np.float64) / nSH
+    Cg = (1e3 * ref).sum(0).real
+    pw = np.einsum("id,ij,jd->d", Y, Cg, Y)
+    raw = pm.rawPmap()
+    assert relrms(raw, pw) < 1e-5
+    az, el = grid[raw.argmax()]
+    assert abs(az - 60.0) < 5 and abs(el - 20.0) < 5
+    m = pm.getPmap().reshape(70, 140)
+    assert m.min() == 0.0 and abs(m.max() - 1.0) < 1e-6
+    r, c = np.unravel_index(m.argmax(), m.shape)
+    assert abs(-180 + c * 360 / 140 - 60) < 5 and abs(-90 + r * 180 / 70 - 20) < 5
