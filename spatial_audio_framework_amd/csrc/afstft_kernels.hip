@@ -159,22 +159,25 @@ __device__ __forceinline__ float2 ana_bin_lo(const float* slot, int k, float2 W)
     return a;
 }
 
-__global__ __launch_bounds__(256, 3) void afstft_analysis_kernel(AnaArgs g)
+/* NCH = channels per workgroup (128 threads each).  NCH = 1 gives twice as many, half as large workgroups: more
+ * independent fold / FFT / store pipelines per CU to overlap with each other. */
+template <int NCH>
+__global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float s_ring[2 * ARING * SLOT];
+    __shared__ __attribute__((aligned(16))) float s_ring[NCH * ARING * SLOT];
     __shared__ float2 s_tw256[130];
     __shared__ float2 s_twJ[8 * 16];
 
     const int tid = threadIdx.x;
     const int inst = blockIdx.z;
-    const int chBase = blockIdx.y * 2;
+    const int chBase = blockIdx.y * NCH;
     const int c0 = blockIdx.x * g.chunk;
     const int c1 = min(c0 + g.chunk, g.a.H);
     if (c0 >= c1) return;
     const int tabStride = g.a.tab_stride ? g.a.tab_stride : g.a.nCh;
     const int T = g.a.hopsPerFrame;
 
-    for (int k = tid; k < 129; k += 256) s_tw256[k] = g.tw256[k];
+    for (int k = tid; k < 129; k += 128 * NCH) s_tw256[k] = g.tw256[k];
     if (tid < 128) s_twJ[tid] = g.twJ[tid];
 
     /* ---- fold role: thread = (channel of the pair, sample position) ---- */
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, 3) void afstft_analysis_kernel(AnaArgs g)
     float2* outBase = g.a.out + (long long)inst * g.a.out_inst + (long long)chBase * g.a.out_ch;
     const unsigned ob32 = (unsigned)g.a.out_band, oc32 = (unsigned)g.a.out_ch;
     const int st = tid & 15, sr = tid >> 4;                /* store role: hop of the sub-chunk, item lane */
-    const int nC = g.a.nCh - chBase >= 2 ? 2 : 1;
+    const int nC = g.a.nCh - chBase >= NCH ? NCH : g.a.nCh - chBase;
 
     int p0 = 6;                                            /* ring position of the sub-chunk's first hop */
     for (int s0 = c0; s0 < c1; s0 += SUB) {
@@ -267,13 +270,17 @@ __global__ __launch_bounds__(256, 3) void afstft_analysis_kernel(AnaArgs g)
 #pragma unroll
             for (int row = 0; row < SAF_ANA_HIST; row++) dst[row * SAF_HOP] = xin[SUB + 9 - SAF_ANA_HIST + row];
         }
-        /* slide the window and prefetch the next sub-chunk's input while the FFT and store phases run */
+        /* slide the window and prefetch the next sub-chunk's input while the FFT phase runs.  The loads land in xl[] and
+         * are consumed (scaled into the window) BEFORE the store phase: vmcnt retires in order, so a wait placed after
+         * the store phase would also wait for every spectrum store on its way to HBM. */
 #pragma unroll
         for (int i = 0; i < 9; i++) xin[i] = xin[i + SUB];
-        if (s0 + SUB < c1 && !(g.dbg & 16)) {
+        float xl[SUB];
+        const bool more = s0 + SUB < c1 && !(g.dbg & 16);
+        if (more) {
 #pragma unroll
             for (int i = 0; i < SUB; i++) {
-                xin[9 + i] = (inBase + curOff)[offIn] * scale;
+                xl[i] = (inBase + curOff)[offIn];
                 if (s0 + SUB + i + 1 < c1) { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += g.a.in_frame - (long long)T * SAF_HOP; } }
             }
         }
@@ -284,6 +291,10 @@ __global__ __launch_bounds__(256, 3) void afstft_analysis_kernel(AnaArgs g)
             fft128_slot<false>(s_ring + (fftC * ARING + pos) * SLOT, fj, twJ);
         }
         lds_barrier();
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < SUB; i++) xin[9 + i] = xl[i] * scale;
+        }
         /* 3. real-FFT split (bins k and 128-k share their inputs), hybrid split + 3-hop delay
          *    (afSTFT_internal.c:523-623), stored time-contiguous: 16 lanes = 16 hops = one 128-byte row segment */
         if (st < n && !(g.dbg & 4)) {
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256, 3) void afstft_analysis_kernel(AnaArgs g)
             if (!g.a.hybrid) pD = pos;                                         /* plain STFT bins, no hybrid delay */
             const unsigned ohop = (unsigned)(s0 + st);
             for (int ii = 0; ii < 9; ii++) {
-                const int item = sr + 16 * ii;
+                const int item = sr + 8 * NCH * ii;
                 if (item >= 65 * nC) break;
                 const int c = item >= 65 ? 1 : 0;
                 const int k = item - 65 * c;
@@ -358,21 +369,23 @@ __global__ __launch_bounds__(256, 3) void afstft_analysis_kernel(AnaArgs g)
 
 struct SynArgs {
     SynLaunch s;
+    int dbg;               /* timing experiments only (SAF_SDBG): bit0 no gather loads, bit1 no FFT, bit2 no overlap-add, bit3 no global stores */
     const float* win;
     const float2* twJ;
     const float2* tw256;
 };
 
-__global__ __launch_bounds__(256, 2) void afstft_synthesis_kernel(SynArgs g)
+template <int NCH>
+__global__ __launch_bounds__(128 * NCH, 2) void afstft_synthesis_kernel(SynArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float s_ring[2 * SUB * SLOT];
+    __shared__ __attribute__((aligned(16))) float s_ring2[2][NCH * SUB * SLOT];     /* double-buffered: sub-chunk i+1 is packed while i is overlap-added */
     __shared__ float2 s_tw256[130];
     __shared__ float2 s_twJ[8 * 16];       /* the overlap-add keeps frame history in registers: twiddles live in LDS here */
 
     const int tid = threadIdx.x;
-    const int chBase = blockIdx.x * 2, inst = blockIdx.y;
+    const int chBase = blockIdx.x * NCH, inst = blockIdx.y;
     const int H = g.s.H;
-    for (int k = tid; k < 129; k += 256) s_tw256[k] = g.tw256[k];
+    for (int k = tid; k < 129; k += 128 * NCH) s_tw256[k] = g.tw256[k];
     if (tid < 128) s_twJ[tid] = g.twJ[tid];
 
     /* overlap-add role: thread = (channel of the pair, sample position n): gl[i] / gr[i] = samples n / 128+n of the
@@ -397,65 +410,78 @@ __global__ __launch_bounds__(256, 2) void afstft_synthesis_kernel(SynArgs g)
     const float2* inBase = g.s.in + (long long)inst * g.s.in_inst + (long long)chBase * g.s.in_ch;
     const unsigned ib32 = (unsigned)g.s.in_band, ic32 = (unsigned)g.s.in_ch;
     const int gt = tid & 15, gr_ = tid >> 4;
-    const int nC = g.s.nCh - chBase >= 2 ? 2 : 1;
+    const int nC = g.s.nCh - chBase >= NCH ? NCH : g.s.nCh - chBase;
     const int T = g.s.hopsPerFrame;
     float* outBase = g.s.out + (long long)inst * g.s.out_inst + (long long)(oOn ? och : 0) * g.s.out_ch + on;
     int oFrame = 0, oSub = 0;                         /* output cursor (uniform): hop -> (frame, hop within the frame) */
 
-    for (int s0 = 0; s0 < H; s0 += SUB) {
-        const int n = min(SUB, H - s0);
-        lds_barrier();
-        /* 1. gather bands -> bins (afHybridInverse, afSTFT_internal.c:625-653) with time-contiguous reads, and
-         *    half-complex -> packed (kiss_fftr.c:125-161; Im of DC/Nyquist ignored): bins k and 128-k give
-         *    2 Z[k] = E + i O and 2 Z[128-k] = conj(E - i O), E = X[k] + conj X[128-k], O = (X[k] - conj X[128-k]) e^{+2 pi i k/256} */
-        if (gt < n) {
-            const unsigned ohop = (unsigned)(s0 + gt);
-            /* all loads of the sub-chunk are issued before the first use: the gather is bound by bytes in flight */
-            /* all loads of the sub-chunk are issued before the first use: the gather is bound by bytes in flight */
-            float2 vXk[9], vXm[9], vX2[2];
+    /* The gather of sub-chunk i+1 is software-pipelined around the FFT of sub-chunk i: its loads are issued before the
+     * FFT and consumed (packed into registers) right after it, BEFORE the overlap-add issues its stores — vmcnt retires
+     * in order, so a wait placed after those stores would also wait for every output sample on its way to HBM. */
+    float2 rXk[9], rXm[9], rX2[2];
+    /* gather bands -> bins (afHybridInverse, afSTFT_internal.c:625-653), time-contiguous reads, unconditional loads */
+    auto issue_gather = [&](int s0n) {
+        const int nn = min(SUB, H - s0n);
+        const unsigned ohop = (unsigned)(s0n + (gt < nn ? gt : 0));
 #pragma unroll
-            for (int i = 0; i < 9; i++) {
-                int item = gr_ + 16 * i; if (item >= 65 * nC) item = 0;
-                const int c = item >= 65 ? 1 : 0;
-                const int k = item - 65 * c;
-                const unsigned o = (unsigned)c * ic32 + ohop;
-                int bk, bm;
-                if (!g.s.hybrid) { bk = k; bm = 128 - k; }
-                else { bm = 132 - k; bk = k == 0 ? 0 : (k < 5 ? 2 * k - 1 : k + 4); }      /* bin k = band 2k-1 (+ band 2k), k = 1..4 */
-                vXk[i] = inBase[(unsigned)bk * ib32 + o];
-                vXm[i] = inBase[(unsigned)bm * ib32 + o];
-                if (i == 0 || i == 4) {          /* the only passes that can hold bins 1..4 (items 1..4 and 66..69) */
-                    const bool pair = g.s.hybrid && k >= 1 && k < 5;
-                    const float2 u = inBase[(unsigned)(pair ? 2 * k : bk) * ib32 + o];
-                    vX2[i >> 2] = pair ? u : make_float2(0.f, 0.f);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                const int item = gr_ + 16 * i;
-                if (item < 65 * nC) {
-                    const int c = item >= 65 ? 1 : 0;
-                    const int k = item - 65 * c;
-                    float2 Xk = vXk[i], Xm = vXm[i];
-                    if (i == 0 || i == 4) { Xk.x += vX2[i >> 2].x; Xk.y += vX2[i >> 2].y; }
-                    /* low-delay mode: odd bins change sign = circular half-frame shift (afSTFT_internal.c:366-369) */
-                    if (g.s.lowDelay && (k & 1)) { Xk.x = -Xk.x; Xk.y = -Xk.y; Xm.x = -Xm.x; Xm.y = -Xm.y; }
-                    if (k == 0) { Xk.y = 0.0f; Xm.y = 0.0f; }
-                    const float2 E = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);
-                    const float2 D = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);
-                    const float2 W = s_tw256[k];
-                    const float2 O = make_float2(D.x * W.x + D.y * W.y, D.y * W.x - D.x * W.y);      /* D * conj(W) */
-                    float* slot = s_ring + (c * SUB + gt) * SLOT;
-                    *reinterpret_cast<float2*>(slot + 2 * k) = make_float2(E.x - O.y, E.y + O.x);
-                    if (k != 0 && k != 64) *reinterpret_cast<float2*>(slot + 2 * (128 - k)) = make_float2(E.x + O.y, O.x - E.y);
-                }
+        for (int i = 0; i < 9; i++) {
+            int item = gr_ + 8 * NCH * i; if (item >= 65 * nC) item = 0;
+            const int c = item >= 65 ? 1 : 0;
+            const int k = item - 65 * c;
+            const unsigned o = (unsigned)c * ic32 + ohop;
+            int bk, bm;
+            if (!g.s.hybrid) { bk = k; bm = 128 - k; }
+            else { bm = 132 - k; bk = k == 0 ? 0 : (k < 5 ? 2 * k - 1 : k + 4); }      /* bin k = band 2k-1 (+ band 2k), k = 1..4 */
+            rXk[i] = inBase[(unsigned)bk * ib32 + o];
+            rXm[i] = inBase[(unsigned)bm * ib32 + o];
+            if (i == 0 || i == 4) {          /* the only passes that can hold bins 1..4 (items 1..4; 66..69 when NCH = 2) */
+                const bool pair = g.s.hybrid && k >= 1 && k < 5;
+                const float2 u = inBase[(unsigned)(pair ? 2 * k : bk) * ib32 + o];
+                rX2[i >> 2] = pair ? u : make_float2(0.f, 0.f);
             }
         }
+    };
+    /* half-complex -> packed (kiss_fftr.c:125-161; Im of DC/Nyquist ignored): bins k and 128-k give
+     * 2 Z[k] = E + i O and 2 Z[128-k] = conj(E - i O), E = X[k] + conj X[128-k], O = (X[k] - conj X[128-k]) e^{+2 pi i k/256};
+     * written to the slot of their hop: Z[k] at floats 2k, 2k+1 */
+    auto pack_gather = [&](float* ring, int nn) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int item = gr_ + 8 * NCH * i;
+            const int itc = item >= 65 * nC ? 0 : item;
+            const int c = itc >= 65 ? 1 : 0;
+            const int k = itc - 65 * c;
+            float2 Xk = rXk[i], Xm = rXm[i];
+            if (i == 0 || i == 4) { Xk.x += rX2[i >> 2].x; Xk.y += rX2[i >> 2].y; }
+            /* low-delay mode: odd bins change sign = circular half-frame shift (afSTFT_internal.c:366-369) */
+            if (g.s.lowDelay && (k & 1)) { Xk.x = -Xk.x; Xk.y = -Xk.y; Xm.x = -Xm.x; Xm.y = -Xm.y; }
+            if (k == 0) { Xk.y = 0.0f; Xm.y = 0.0f; }
+            const float2 E = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);
+            const float2 D = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);
+            const float2 W = s_tw256[k];
+            const float2 O = make_float2(D.x * W.x + D.y * W.y, D.y * W.x - D.x * W.y);      /* D * conj(W) */
+            if (gt < nn && item < 65 * nC) {
+                float* slot = ring + (c * SUB + gt) * SLOT;
+                *reinterpret_cast<float2*>(slot + 2 * k) = make_float2(E.x - O.y, E.y + O.x);
+                if (k != 0 && k != 64) *reinterpret_cast<float2*>(slot + 2 * (128 - k)) = make_float2(E.x + O.y, O.x - E.y);
+            }
+        }
+    };
+    issue_gather(0);
+    lds_barrier();                                    /* s_tw256 is in place */
+    pack_gather(s_ring2[0], min(SUB, H));
+
+    for (int s0 = 0, it = 0; s0 < H; s0 += SUB, it++) {
+        const int n = min(SUB, H - s0);
+        const bool more = s0 + SUB < H;
+        float* s_ring = s_ring2[it & 1];
         lds_barrier();
+        if (more && !(g.dbg & 1)) issue_gather(s0 + SUB);
         /* 2. 128-point inverse FFT in place: frame sample 2m, 2m+1 = Re, Im z[m] (x 1/256 in the overlap-add:
          *    1/2 of the packing above and the 1/128 of saf_rfft_backward's 1/N, saf_utility_fft.c:751) */
-        if (fftT < n) fft128_slot<true>(s_ring + (fftC * SUB + fftT) * SLOT, fj, twJ);
+        if (fftT < n && !(g.dbg & 2)) fft128_slot<true>(s_ring + (fftC * SUB + fftT) * SLOT, fj, twJ);
         lds_barrier();
+        if (more) pack_gather(s_ring2[(it + 1) & 1], min(SUB, H - s0 - SUB));
         /* 3. 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0+t is
          *    sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n] */
         {
@@ -463,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void afstft_synthesis_kernel(SynArgs g)
 #pragma unroll
             for (int half = 0; half < SUB / OLA; half++) {
                 const int nh = min(OLA, n - half * OLA);          /* hops of this pass (<= 0: nothing left) */
-                if (nh <= 0) break;
+                if (nh <= 0 || (g.dbg & 4)) break;
 #pragma unroll
                 for (int u = 0; u < OLA; u++) {
                     if (u < nh) {
@@ -473,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void afstft_synthesis_kernel(SynArgs g)
                         float acc = 0.0f;
 #pragma unroll
                         for (int k = 9; k >= 0; k--) acc = fmaf(wn[k], (k & 1) ? gr[9 + u - k] : gl[9 + u - k], acc);
-                        if (oOn) outBase[(long long)oFrame * g.s.out_frame + oSub * SAF_HOP] = acc;
+                        if (oOn && !((g.dbg & 8) && acc != 123.456f)) outBase[(long long)oFrame * g.s.out_frame + oSub * SAF_HOP] = acc;
                         oSub++; if (oSub == T) { oSub = 0; oFrame++; }
                     }
                 }
@@ -556,8 +582,9 @@ void launch_analysis(const AnaLaunch& a)
     /* Time chunks add parallelism when few (instance, channel pair) workgroups are in flight, but every extra chunk
      * recomputes 6 warm-up FFTs.  Chunks are multiples of 16 hops (aligned 128-byte row segments).  Pick the chunk
      * count that minimises (rounds over the chip) x (sub-chunks per workgroup); 3 workgroups per CU on 256 CUs. */
-    const long long groups = (long long)((a.nCh + 1) / 2) * a.nInst;
-    const long long slots = 3 * 256;
+    const int NCHW = 1;                                   /* channels per workgroup */
+    const long long groups = (long long)((a.nCh + NCHW - 1) / NCHW) * a.nInst;
+    const long long slots = (6 / NCHW) * 256;
     int chunk = a.H;
     {
         long long best = -1;
@@ -572,9 +599,9 @@ void launch_analysis(const AnaLaunch& a)
     g.chunk = chunk;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SAF_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     { static int fc = -1; if (fc < 0) { const char* e = getenv("SAF_CHUNK"); fc = e ? atoi(e) : 0; } if (fc > 0) g.chunk = fc; }
-    dim3 grid((a.H + g.chunk - 1) / g.chunk, (a.nCh + 1) / 2, a.nInst);
+    dim3 grid((a.H + g.chunk - 1) / g.chunk, (a.nCh + NCHW - 1) / NCHW, a.nInst);
     KernelTimer kt("afstft_analysis");
-    hipLaunchKernelGGL(afstft_analysis_kernel, grid, dim3(256), 0, stream(), g);
+    hipLaunchKernelGGL(afstft_analysis_kernel<NCHW>, grid, dim3(128 * NCHW), 0, stream(), g);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -583,12 +610,14 @@ void launch_synthesis(const SynLaunch& s)
     if (s.H <= 0 || s.nCh <= 0 || s.nInst <= 0) return;
     SynArgs g;
     g.s = s;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SAF_SDBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     g.win = dev_window(s.lowDelay, 1);
     g.twJ = dev_twiddles();
     g.tw256 = g.twJ + 128;
-    dim3 grid((s.nCh + 1) / 2, s.nInst);
+    const int NCHW = 1;                                   /* channels per workgroup */
+    dim3 grid((s.nCh + NCHW - 1) / NCHW, s.nInst);
     KernelTimer kt("afstft_synthesis");
-    hipLaunchKernelGGL(afstft_synthesis_kernel, grid, dim3(256), 0, stream(), g);
+    hipLaunchKernelGGL(afstft_synthesis_kernel<NCHW>, grid, dim3(128 * NCHW), 0, stream(), g);
     HIP_CHECK(hipGetLastError());
 }
 
