@@ -14,15 +14,24 @@
  * 6 more for the hybrid half-band FIR and its 3-hop delay) and (b) the last 9
  * synthesised frames for the 10-segment overlap-add.
  *
- * Mapping: one workgroup (4 waves) per (instance, channel PAIR[, hop chunk]), working through the
- * hops in sub-chunks of 16.  Per sub-chunk three phases share one LDS ring of 1 KiB spectrum slots:
- *   analysis : window fold (thread = sample position, sliding 10-hop register window, input read once
- *              from HBM)  ->  32 FFTs  ->  hybrid split + time-contiguous store of [band][ch][hop]
- *   synthesis: time-contiguous gather + hybrid merge  ->  32 inverse FFTs  ->  10-segment overlap-add
- *              (thread = sample position, frame history in registers)
- * The 256-point real FFT is a 128-point complex FFT done by 8 lanes x 16 points: a radix-4x4 DFT-16
- * in registers, the W128 twiddles, an 8x16 transpose through the FFT's own LDS slot (XOR-swizzled,
- * conflict-free), two DFT-8 in registers.  No cross-lane shuffles, ~45 wave-instructions per FFT.
+ * Both kernels work through the hops of a launch in sub-chunks of 16 and keep the sub-chunk's spectra in an LDS ring
+ * of 1 KiB slots (one slot = one hop of one channel):
+ *   analysis  : workgroup = (instance, channel[, hop chunk]), 2 waves.  Per sub-chunk: window fold (thread = sample
+ *               position, sliding 10-hop register window, every input sample read once from HBM, next sub-chunk's
+ *               loads in flight under the FFT)  ->  16 FFTs  ->  real-FFT split (bins k and 128-k share their inputs),
+ *               hybrid split and time-contiguous store of [band][ch][hop] (16 lanes = one 128-byte row segment).
+ *   synthesis : workgroup = (instance, channel), 4 waves, wave-specialised: two producer waves gather the
+ *               time-contiguous band rows of sub-chunk i+1, merge the hybrid bands, pack and inverse-FFT them into one
+ *               LDS buffer while two consumer waves run the 10-segment overlap-add of sub-chunk i (thread = sample
+ *               position, frame history in registers) out of the other buffer.
+ * The 256-point real FFT is a 128-point complex FFT done by 8 lanes x 16 points: a radix-4x4 DFT-16 in registers, the
+ * W128 twiddles, an 8x16 transpose through the FFT's own LDS slot (XOR-swizzled, conflict-free), two DFT-8 in
+ * registers.  No cross-lane shuffles, ~45 wave-instructions per FFT.
+ *
+ * Lessons that shaped the code (measured on MI355X, profiles/): (1) a global load under a branch gets its own wait:
+ * every load here is unconditional (clamped address, masked value); (2) __syncthreads() also drains vmcnt, so the
+ * barriers order LDS only; (3) vmcnt retires in order: prefetched loads are consumed BEFORE the phase that issues the
+ * spectrum / sample stores, otherwise their wait also waits for those stores to reach HBM.
  */
 #include "saf_hip_common.h"
 
@@ -137,7 +146,6 @@ struct AnaArgs {
     const float2* twJ;     /* [8][16]  exp(-2 pi i j p / 128) */
     const float2* tw256;   /* [129]    exp(-2 pi i k / 256) */
     int chunk;
-    int dbg;               /* timing experiments only (SAF_DBG): bit0 no fold, bit1 no FFT, bit2 no store phase, bit3 no global stores, bit4 no prefetch */
 };
 
 /* bins k and 128-k (k = 0..64) of the 256-point real FFT from the packed 128-point spectrum in an LDS slot
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
         /* 1. window + fold (afSTFT_internal.c:276-301): f[(k&1)*128 + n] = sum_k x[hop-9+k][n] * w[k*128+n] */
 #pragma unroll
         for (int t = 0; t < SUB; t++) {
-            if (t < n && !(g.dbg & 1)) {
+            if (t < n) {
                 float fe = 0.0f, fo = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
 #pragma unroll
         for (int i = 0; i < 9; i++) xin[i] = xin[i + SUB];
         float xl[SUB];
-        const bool more = s0 + SUB < c1 && !(g.dbg & 16);
+        const bool more = s0 + SUB < c1;
         if (more) {
 #pragma unroll
             for (int i = 0; i < SUB; i++) {
@@ -286,7 +294,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
         }
         lds_barrier();
         /* 2. 256-point real FFT as a 128-point complex FFT of z[m] = f[2m] + i f[2m+1], in place in the slot */
-        if (fftT < n && !(g.dbg & 2)) {
+        if (fftT < n) {
             int pos = p0 + fftT; if (pos >= ARING) pos -= ARING;
             fft128_slot<false>(s_ring + (fftC * ARING + pos) * SLOT, fj, twJ);
         }
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
         }
         /* 3. real-FFT split (bins k and 128-k share their inputs), hybrid split + 3-hop delay
          *    (afSTFT_internal.c:523-623), stored time-contiguous: 16 lanes = 16 hops = one 128-byte row segment */
-        if (st < n && !(g.dbg & 4)) {
+        if (st < n) {
             int pos = p0 + st; if (pos >= ARING) pos -= ARING;                 /* ring position of S_hop */
             int pD = pos - 3; if (pD < 0) pD += ARING;                         /* all bands are delayed 3 hops */
             if (!g.a.hybrid) pD = pos;                                         /* plain STFT bins, no hybrid delay */
@@ -312,7 +320,6 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
                 float2 Xk, Xm;
                 ana_bin_pair(ring + pD * SLOT, k, W, Xk, Xm);
                 const unsigned o = (unsigned)c * oc32 + ohop;
-                if (g.dbg & 8) { if (Xk.x == 123.456f) outBase[o] = Xm; continue; }
                 if (!g.a.hybrid) {
                     outBase[(unsigned)k * ob32 + o] = Xk;
                     if (k != 64) outBase[(unsigned)(128 - k) * ob32 + o] = Xm;
@@ -369,160 +376,151 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
 
 struct SynArgs {
     SynLaunch s;
-    int dbg;               /* timing experiments only (SAF_SDBG): bit0 no gather loads, bit1 no FFT, bit2 no overlap-add, bit3 no global stores */
     const float* win;
     const float2* twJ;
     const float2* tw256;
 };
 
-template <int NCH>
-__global__ __launch_bounds__(128 * NCH, 2) void afstft_synthesis_kernel(SynArgs g)
+/* Wave-specialised synthesis: one output channel per workgroup of 4 waves.
+ *   waves 0-1 (producer): gather + hybrid merge + half-complex packing of sub-chunk i+1 into one LDS buffer, then its 16
+ *                         inverse FFTs in place;
+ *   waves 2-3 (consumer): 10-segment overlap-add of sub-chunk i from the other buffer, one thread per sample position,
+ *                         frame history in registers, output stores.
+ * The two roles need different registers (gather staging + FFT temporaries vs. the overlap-add window), so the kernel's
+ * register count is the larger of the two instead of their sum, and they overlap in time: while the producer's loads are
+ * in flight and its FFT runs, the consumer streams the previous sub-chunk out.  Two workgroup barriers per sub-chunk. */
+__global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
 {
-    __shared__ __attribute__((aligned(16))) float s_ring2[2][NCH * SUB * SLOT];     /* double-buffered: sub-chunk i+1 is packed while i is overlap-added */
+    __shared__ __attribute__((aligned(16))) float s_buf[2][SUB * SLOT];
     __shared__ float2 s_tw256[130];
-    __shared__ float2 s_twJ[8 * 16];       /* the overlap-add keeps frame history in registers: twiddles live in LDS here */
+    __shared__ float2 s_twJ[8 * 16];
 
     const int tid = threadIdx.x;
-    const int chBase = blockIdx.x * NCH, inst = blockIdx.y;
+    const int ch = blockIdx.x, inst = blockIdx.y;
     const int H = g.s.H;
-    for (int k = tid; k < 129; k += 128 * NCH) s_tw256[k] = g.tw256[k];
+    const int nSub = (H + SUB - 1) / SUB;
+    const bool producer = tid < 128;
+    for (int k = tid; k < 129; k += 256) s_tw256[k] = g.tw256[k];
     if (tid < 128) s_twJ[tid] = g.twJ[tid];
 
-    /* overlap-add role: thread = (channel of the pair, sample position n): gl[i] / gr[i] = samples n / 128+n of the
-     * frame synthesised at hop h0 - 9 + i */
-    const int oc = tid >> 7, on = tid & 127;
-    const int och = chBase + oc;
-    const bool oOn = och < g.s.nCh;
-    float wn[10], gl[OLA + 9], gr[OLA + 9];     /* OLA = hops per overlap-add pass (static register window) */
+    if (producer) {
+        const int ff = tid >> 3, fj = tid & 7;                    /* FFT role: 16 FFTs x 8 lanes */
+        const float2* twJ = s_twJ + fj * 16;
+        const float2* inBase = g.s.in + (long long)inst * g.s.in_inst + (long long)ch * g.s.in_ch;
+        const unsigned ib32 = (unsigned)g.s.in_band;
+        const int gt = tid & 15, gq = tid >> 4;                   /* gather role: hop of the sub-chunk, item lane (8) */
+        for (int it = -1; it <= nSub; it++) {
+            const int s0 = it * SUB;
+            if (it >= 0 && it < nSub) {
+                /* gather bands -> bins (afHybridInverse, afSTFT_internal.c:625-653): time-contiguous reads, unconditional
+                 * loads, all issued before the first use; item = bin pair (k, 128-k), k = gq + 8 i.  The load latency is
+                 * covered by the consumer waves, which are busy with the previous sub-chunk. */
+                const int nn = min(SUB, H - s0);
+                const unsigned ohop = (unsigned)(s0 + (gt < nn ? gt : 0));
+                float2 rXk[9], rXm[9], rX2 = make_float2(0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < 10; k++) wn[k] = g.win[k * SAF_HOP + on];
-    {
-        const float* h = g.s.hist_rd + ((long long)inst * g.s.nCh + (oOn ? och : 0)) * SAF_SYN_HIST * 256;
+                for (int i = 0; i < 9; i++) {
+                    int k = gq + 8 * i; if (k > 64) k = 0;
+                    int bk, bm;
+                    if (!g.s.hybrid) { bk = k; bm = 128 - k; }
+                    else { bm = 132 - k; bk = k == 0 ? 0 : (k < 5 ? 2 * k - 1 : k + 4); }      /* bin k = band 2k-1 (+ band 2k), k = 1..4 */
+                    rXk[i] = inBase[(unsigned)bk * ib32 + ohop];
+                    rXm[i] = inBase[(unsigned)bm * ib32 + ohop];
+                    if (i == 0) {                   /* the only pass that can hold bins 1..4 */
+                        const bool pair = g.s.hybrid && k >= 1 && k < 5;
+                        const float2 u = inBase[(unsigned)(pair ? 2 * k : bk) * ib32 + ohop];
+                        rX2 = pair ? u : make_float2(0.f, 0.f);
+                    }
+                }
+                /* half-complex -> packed (kiss_fftr.c:125-161; Im of DC/Nyquist ignored): bins k and 128-k give
+                 * 2 Z[k] = E + i O and 2 Z[128-k] = conj(E - i O), E = X[k] + conj X[128-k], O = (X[k] - conj X[128-k]) e^{+2 pi i k/256} */
+                float* ring = s_buf[it & 1];
 #pragma unroll
-        for (int i = 0; i < 9; i++) { gl[i] = h[i * 256 + on]; gr[i] = h[i * 256 + 128 + on]; }
-#pragma unroll
-        for (int i = 9; i < OLA + 9; i++) gl[i] = gr[i] = 0.0f;
-    }
-    const int ff = tid >> 3, fj = tid & 7;
-    const int fftC = ff >> 4, fftT = ff & 15;
-    const float2* twJ = s_twJ + fj * 16;
-
-    const float2* inBase = g.s.in + (long long)inst * g.s.in_inst + (long long)chBase * g.s.in_ch;
-    const unsigned ib32 = (unsigned)g.s.in_band, ic32 = (unsigned)g.s.in_ch;
-    const int gt = tid & 15, gr_ = tid >> 4;
-    const int nC = g.s.nCh - chBase >= NCH ? NCH : g.s.nCh - chBase;
-    const int T = g.s.hopsPerFrame;
-    float* outBase = g.s.out + (long long)inst * g.s.out_inst + (long long)(oOn ? och : 0) * g.s.out_ch + on;
-    int oFrame = 0, oSub = 0;                         /* output cursor (uniform): hop -> (frame, hop within the frame) */
-
-    /* The gather of sub-chunk i+1 is software-pipelined around the FFT of sub-chunk i: its loads are issued before the
-     * FFT and consumed (packed into registers) right after it, BEFORE the overlap-add issues its stores — vmcnt retires
-     * in order, so a wait placed after those stores would also wait for every output sample on its way to HBM. */
-    float2 rXk[9], rXm[9], rX2[2];
-    /* gather bands -> bins (afHybridInverse, afSTFT_internal.c:625-653), time-contiguous reads, unconditional loads */
-    auto issue_gather = [&](int s0n) {
-        const int nn = min(SUB, H - s0n);
-        const unsigned ohop = (unsigned)(s0n + (gt < nn ? gt : 0));
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            int item = gr_ + 8 * NCH * i; if (item >= 65 * nC) item = 0;
-            const int c = item >= 65 ? 1 : 0;
-            const int k = item - 65 * c;
-            const unsigned o = (unsigned)c * ic32 + ohop;
-            int bk, bm;
-            if (!g.s.hybrid) { bk = k; bm = 128 - k; }
-            else { bm = 132 - k; bk = k == 0 ? 0 : (k < 5 ? 2 * k - 1 : k + 4); }      /* bin k = band 2k-1 (+ band 2k), k = 1..4 */
-            rXk[i] = inBase[(unsigned)bk * ib32 + o];
-            rXm[i] = inBase[(unsigned)bm * ib32 + o];
-            if (i == 0 || i == 4) {          /* the only passes that can hold bins 1..4 (items 1..4; 66..69 when NCH = 2) */
-                const bool pair = g.s.hybrid && k >= 1 && k < 5;
-                const float2 u = inBase[(unsigned)(pair ? 2 * k : bk) * ib32 + o];
-                rX2[i >> 2] = pair ? u : make_float2(0.f, 0.f);
+                for (int i = 0; i < 9; i++) {
+                    const int kk = gq + 8 * i;
+                    const int k = kk > 64 ? 0 : kk;
+                    float2 Xk = rXk[i], Xm = rXm[i];
+                    if (i == 0) { Xk.x += rX2.x; Xk.y += rX2.y; }
+                    /* low-delay mode: odd bins change sign = circular half-frame shift (afSTFT_internal.c:366-369) */
+                    if (g.s.lowDelay && (k & 1)) { Xk.x = -Xk.x; Xk.y = -Xk.y; Xm.x = -Xm.x; Xm.y = -Xm.y; }
+                    if (k == 0) { Xk.y = 0.0f; Xm.y = 0.0f; }
+                    const float2 E = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);
+                    const float2 D = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);
+                    const float2 W = s_tw256[k];
+                    const float2 O = make_float2(D.x * W.x + D.y * W.y, D.y * W.x - D.x * W.y);      /* D * conj(W) */
+                    if (gt < nn && kk <= 64) {
+                        float* slot = ring + gt * SLOT;
+                        *reinterpret_cast<float2*>(slot + 2 * k) = make_float2(E.x - O.y, E.y + O.x);
+                        if (k != 0 && k != 64) *reinterpret_cast<float2*>(slot + 2 * (128 - k)) = make_float2(E.x + O.y, O.x - E.y);
+                    }
+                }
             }
+            lds_barrier();                                       /* (A) */
+            /* 128-point inverse FFT in place: frame sample 2m, 2m+1 = Re, Im z[m] (x 1/256 in the overlap-add: 1/2 of the
+             * packing above and the 1/128 of saf_rfft_backward's 1/N, saf_utility_fft.c:751) */
+            if (it >= 0 && it < nSub && ff < min(SUB, H - s0)) fft128_slot<true>(s_buf[it & 1] + ff * SLOT, fj, twJ);
+            lds_barrier();                                       /* (B) */
         }
-    };
-    /* half-complex -> packed (kiss_fftr.c:125-161; Im of DC/Nyquist ignored): bins k and 128-k give
-     * 2 Z[k] = E + i O and 2 Z[128-k] = conj(E - i O), E = X[k] + conj X[128-k], O = (X[k] - conj X[128-k]) e^{+2 pi i k/256};
-     * written to the slot of their hop: Z[k] at floats 2k, 2k+1 */
-    auto pack_gather = [&](float* ring, int nn) {
+    } else {
+        /* overlap-add role: thread = sample position n: gl[i] / gr[i] = samples n / 128+n of the frame of hop h0 - 9 + i */
+        const int on = tid - 128;
+        const int T = g.s.hopsPerFrame;
+        float wn[10], gl[OLA + 9], gr[OLA + 9];
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const int item = gr_ + 8 * NCH * i;
-            const int itc = item >= 65 * nC ? 0 : item;
-            const int c = itc >= 65 ? 1 : 0;
-            const int k = itc - 65 * c;
-            float2 Xk = rXk[i], Xm = rXm[i];
-            if (i == 0 || i == 4) { Xk.x += rX2[i >> 2].x; Xk.y += rX2[i >> 2].y; }
-            /* low-delay mode: odd bins change sign = circular half-frame shift (afSTFT_internal.c:366-369) */
-            if (g.s.lowDelay && (k & 1)) { Xk.x = -Xk.x; Xk.y = -Xk.y; Xm.x = -Xm.x; Xm.y = -Xm.y; }
-            if (k == 0) { Xk.y = 0.0f; Xm.y = 0.0f; }
-            const float2 E = make_float2(Xk.x + Xm.x, Xk.y - Xm.y);
-            const float2 D = make_float2(Xk.x - Xm.x, Xk.y + Xm.y);
-            const float2 W = s_tw256[k];
-            const float2 O = make_float2(D.x * W.x + D.y * W.y, D.y * W.x - D.x * W.y);      /* D * conj(W) */
-            if (gt < nn && item < 65 * nC) {
-                float* slot = ring + (c * SUB + gt) * SLOT;
-                *reinterpret_cast<float2*>(slot + 2 * k) = make_float2(E.x - O.y, E.y + O.x);
-                if (k != 0 && k != 64) *reinterpret_cast<float2*>(slot + 2 * (128 - k)) = make_float2(E.x + O.y, O.x - E.y);
-            }
-        }
-    };
-    issue_gather(0);
-    lds_barrier();                                    /* s_tw256 is in place */
-    pack_gather(s_ring2[0], min(SUB, H));
-
-    for (int s0 = 0, it = 0; s0 < H; s0 += SUB, it++) {
-        const int n = min(SUB, H - s0);
-        const bool more = s0 + SUB < H;
-        float* s_ring = s_ring2[it & 1];
-        lds_barrier();
-        if (more && !(g.dbg & 1)) issue_gather(s0 + SUB);
-        /* 2. 128-point inverse FFT in place: frame sample 2m, 2m+1 = Re, Im z[m] (x 1/256 in the overlap-add:
-         *    1/2 of the packing above and the 1/128 of saf_rfft_backward's 1/N, saf_utility_fft.c:751) */
-        if (fftT < n && !(g.dbg & 2)) fft128_slot<true>(s_ring + (fftC * SUB + fftT) * SLOT, fj, twJ);
-        lds_barrier();
-        if (more) pack_gather(s_ring2[(it + 1) & 1], min(SUB, H - s0 - SUB));
-        /* 3. 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0+t is
-         *    sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n] */
+        for (int k = 0; k < 10; k++) wn[k] = g.win[k * SAF_HOP + on];
         {
-            const float sc = 1.0f / 256.0f;
+            const float* h = g.s.hist_rd + ((long long)inst * g.s.nCh + ch) * SAF_SYN_HIST * 256;
 #pragma unroll
-            for (int half = 0; half < SUB / OLA; half++) {
-                const int nh = min(OLA, n - half * OLA);          /* hops of this pass (<= 0: nothing left) */
-                if (nh <= 0 || (g.dbg & 4)) break;
+            for (int i = 0; i < 9; i++) { gl[i] = h[i * 256 + on]; gr[i] = h[i * 256 + 128 + on]; }
 #pragma unroll
-                for (int u = 0; u < OLA; u++) {
-                    if (u < nh) {
-                        const int t = half * OLA + u;
-                        const float* slot = s_ring + (oc * SUB + t) * SLOT;
-                        gl[9 + u] = slot[on] * sc; gr[9 + u] = slot[128 + on] * sc;
-                        float acc = 0.0f;
+            for (int i = 9; i < OLA + 9; i++) gl[i] = gr[i] = 0.0f;
+        }
+        float* outBase = g.s.out + (long long)inst * g.s.out_inst + (long long)ch * g.s.out_ch + on;
+        int oFrame = 0, oSub = 0;                                /* output cursor (uniform): hop -> (frame, hop within the frame) */
+        const float sc = 1.0f / 256.0f;
+        /* 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0+t is
+         * sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n]; one pass of OLA = 8 hops per barrier interval */
+        for (int it = -1; it <= nSub; it++) {
+            const int sp = (it - 1) * SUB;                       /* sub-chunk being emitted */
+            const int np = it >= 1 ? min(SUB, H - sp) : 0;
+            const float* ring = s_buf[(it + 1) & 1];
 #pragma unroll
-                        for (int k = 9; k >= 0; k--) acc = fmaf(wn[k], (k & 1) ? gr[9 + u - k] : gl[9 + u - k], acc);
-                        if (oOn && !((g.dbg & 8) && acc != 123.456f)) outBase[(long long)oFrame * g.s.out_frame + oSub * SAF_HOP] = acc;
-                        oSub++; if (oSub == T) { oSub = 0; oFrame++; }
+            for (int half = 0; half < SUB / OLA; half++) {       /* one pass of OLA = 8 hops per barrier interval */
+                const int nh = min(OLA, np - half * OLA);
+                if (nh > 0) {
+#pragma unroll
+                    for (int u = 0; u < OLA; u++) {
+                        if (u < nh) {
+                            const float* slot = ring + (half * OLA + u) * SLOT;
+                            gl[9 + u] = slot[on] * sc; gr[9 + u] = slot[128 + on] * sc;
+                            float acc = 0.0f;
+#pragma unroll
+                            for (int k = 9; k >= 0; k--) acc = fmaf(wn[k], (k & 1) ? gr[9 + u - k] : gl[9 + u - k], acc);
+                            outBase[(long long)oFrame * g.s.out_frame + oSub * SAF_HOP] = acc;
+                            oSub++; if (oSub == T) { oSub = 0; oFrame++; }
+                        }
+                    }
+                    if (nh == OLA) {
+#pragma unroll
+                        for (int i = 0; i < 9; i++) { gl[i] = gl[i + OLA]; gr[i] = gr[i + OLA]; }
+                    } else {                                     /* partial pass: the 9 newest frames sit at nh .. nh+8 */
+#pragma unroll
+                        for (int i = 0; i < 9; i++) {
+                            float a = gl[i], b = gr[i];
+#pragma unroll
+                            for (int q = 1; q < OLA; q++) if (q == nh) { a = gl[i + q]; b = gr[i + q]; }
+                            gl[i] = a; gr[i] = b;
+                        }
                     }
                 }
-                /* slide the window: the 9 newest frames sit at indices nh .. nh+8 */
-                if (nh == OLA) {
-#pragma unroll
-                    for (int i = 0; i < 9; i++) { gl[i] = gl[i + OLA]; gr[i] = gr[i + OLA]; }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 9; i++) {
-                        float a = gl[i], b = gr[i];
-#pragma unroll
-                        for (int q = 1; q < OLA; q++) if (q == nh) { a = gl[i + q]; b = gr[i + q]; }
-                        gl[i] = a; gr[i] = b;
-                    }
-                }
+                lds_barrier();                                   /* (A) after the first pass, (B) after the second */
             }
         }
-    }
-    if (oOn && g.s.hist_wr) {
-        float* h = g.s.hist_wr + ((long long)inst * g.s.nCh + och) * SAF_SYN_HIST * 256;
+        if (g.s.hist_wr) {
+            float* h = g.s.hist_wr + ((long long)inst * g.s.nCh + ch) * SAF_SYN_HIST * 256;
 #pragma unroll
-        for (int i = 0; i < 9; i++) { h[i * 256 + on] = gl[i]; h[i * 256 + 128 + on] = gr[i]; }
+            for (int i = 0; i < 9; i++) { h[i * 256 + on] = gl[i]; h[i * 256 + 128 + on] = gr[i]; }
+        }
     }
 }
 
@@ -597,8 +595,6 @@ void launch_analysis(const AnaLaunch& a)
         }
     }
     g.chunk = chunk;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SAF_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
-    { static int fc = -1; if (fc < 0) { const char* e = getenv("SAF_CHUNK"); fc = e ? atoi(e) : 0; } if (fc > 0) g.chunk = fc; }
     dim3 grid((a.H + g.chunk - 1) / g.chunk, (a.nCh + NCHW - 1) / NCHW, a.nInst);
     KernelTimer kt("afstft_analysis");
     hipLaunchKernelGGL(afstft_analysis_kernel<NCHW>, grid, dim3(128 * NCHW), 0, stream(), g);
@@ -610,14 +606,12 @@ void launch_synthesis(const SynLaunch& s)
     if (s.H <= 0 || s.nCh <= 0 || s.nInst <= 0) return;
     SynArgs g;
     g.s = s;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SAF_SDBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
     g.win = dev_window(s.lowDelay, 1);
     g.twJ = dev_twiddles();
     g.tw256 = g.twJ + 128;
-    const int NCHW = 1;                                   /* channels per workgroup */
-    dim3 grid((s.nCh + NCHW - 1) / NCHW, s.nInst);
+    dim3 grid(s.nCh, s.nInst);
     KernelTimer kt("afstft_synthesis");
-    hipLaunchKernelGGL(afstft_synthesis_kernel<NCHW>, grid, dim3(128 * NCHW), 0, stream(), g);
+    hipLaunchKernelGGL(afstft_synthesis_ws_kernel, grid, dim3(256), 0, stream(), g);
     HIP_CHECK(hipGetLastError());
 }
 
