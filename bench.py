@@ -95,19 +95,14 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
+    from spatial_audio_framework_amd import parallel as P
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    world, rank, local_rank = P.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    P.init(backend="nccl", device=dev)          # RCCL; ranks only meet in the barriers and the MAX of the elapsed time
 
     from spatial_audio_framework_amd import api
     from spatial_audio_framework_amd._lib import load
@@ -133,21 +128,16 @@ def main():
     torch.cuda.synchronize()
     L.saf_hip_profile_reset()
     L.saf_hip_profile_enable(0 if args.no_profile else 1)
-    if world > 1:
-        dist.barrier()
+    P.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    P.barrier()
     elapsed = time.perf_counter() - t0
     L.saf_hip_profile_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = P.max_over_ranks(elapsed, device=dev)
 
     frames_total = world * nI * nF * args.steps
     value = frames_total / elapsed
@@ -167,9 +157,11 @@ def main():
                 frames_per_launch = nI * nF
                 traffic = None
                 tf = ROOT / "profiles" / "traffic_latest.json"
-                if tf.exists():
+                if tf.exists():          # PMC bytes per launch, measured at a given launch size (tools/gpu_profile.sh)
                     try:
-                        traffic = json.loads(tf.read_text()).get(dom, {}).get("hbm_bytes_per_launch")
+                        tj = json.loads(tf.read_text())
+                        if tj.get("frames_per_launch") == frames_per_launch:
+                            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
                     except Exception:
                         traffic = None
                 if dom == "band_gemm":
@@ -201,9 +193,7 @@ def main():
         if cpu:
             line["speedup_vs_cpu_1core"] = round(value / cpu["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    P.finalize()
 
 
 if __name__ == "__main__":

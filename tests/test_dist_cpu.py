@@ -1,0 +1,89 @@
+"""The N > 1 path on CPU: world-size-2 `gloo` process groups on 127.0.0.1 (no GPU needed).
+
+Instances are independent, so N ranks each run their shard of the instances with no data-path collective;
+ranks meet in barriers, one MAX all-reduce of the elapsed time and the gathering of results.  Here each rank renders
+its shard of encode -> decode scenes with the CPU oracle (the checker), the shards are gathered, and the result must
+equal the single-process rendering of all scenes — plus the bookkeeping `bench.py` relies on.
+"""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def render_scene(O, scene, nFrames=3, F=128):
+    """One independent unit: 4 sources -> ambi_enc (order 1) -> ambi_dec (t-design-4) -> checksum-able output."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from util import frames
+    e = O.AmbiEnc(F); e.init(48000); e.setOutputOrder(1); e.setNumSources(4); e.setNormType(1)
+    for s in range(4):
+        e.setSourceAzi_deg(s, float((37 * scene + 90 * s) % 360 - 180)); e.setSourceElev_deg(s, float((11 * scene + 20 * s) % 120 - 60))
+    d = O.AmbiDec(F); d.setNormType(1); d.setMasterDecOrder(1); d.setOutputConfigPreset(19)
+    d.setDecMethod(0, 1); d.setDecMethod(1, 1); d.initCodec(); d.init(48000)
+    x = frames(100 + scene, 4, nFrames * F)
+    out = []
+    for f in range(nFrames):
+        sh = e.process(x[:, f * F:(f + 1) * F], 4)
+        out.append(d.process(sh, 4))
+    return np.concatenate(out, 1)
+
+
+def _worker(rank, world, port, nScenes, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    from spatial_audio_framework_amd import parallel as P
+    from oracle import oracle as O
+    w, r, _ = P.init(backend="gloo")
+    assert (w, r) == (world, rank)
+    mine = P.shard(nScenes, world, rank)
+    P.barrier()
+    local = np.stack([render_scene(O, s) for s in mine]) if len(mine) else np.zeros((0, 4, 384), np.float32)
+    P.barrier()
+    elapsed = 1.0 + rank                                    # the slowest rank defines the job time
+    t_max = P.max_over_ranks(elapsed)
+    n_total = P.sum_over_ranks(len(mine))
+    everything = P.gather_arrays(local)                     # equal shard sizes in this test (nScenes % world == 0)
+    if rank == 0:
+        q.put((t_max, n_total, everything))
+    P.finalize()
+
+
+def test_two_rank_gloo_sharding_matches_single_process():
+    nScenes, world = 6, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nScenes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    t_max, n_total, gathered = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert t_max == 2.0 and n_total == nScenes
+    sys.path.insert(0, str(ROOT))
+    from oracle import oracle as O
+    ref = np.stack([render_scene(O, s) for s in range(nScenes)])
+    assert gathered.shape == ref.shape and np.array_equal(gathered, ref)     # no cross-talk, rank order preserved
+
+
+def test_shard_partition_properties():
+    sys.path.insert(0, str(ROOT))
+    from spatial_audio_framework_amd.parallel import shard
+    for n in (0, 1, 7, 32, 2048):
+        for world in (1, 2, 3, 8):
+            parts = [list(shard(n, world, r)) for r in range(world)]
+            assert sum(parts, []) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1

@@ -13,12 +13,16 @@ READ_CORR = {   # kernel -> (factor, note)
     "afstft_analysis_kernel": (2.0, "4 B/lane loads, 256 B contiguous per wave: x 2 (face value would be below the input bytes alone)"),
 }
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in sys.argv[1:]:
+frames_per_launch = None
+args = sys.argv[1:]
+if args and args[0].startswith("--frames-per-launch="):
+    frames_per_launch = int(args.pop(0).split("=")[1])
+for d in args:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0].split("<")[0].replace("saf::", "").replace("void ", "")
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-out = {}
+out = {"frames_per_launch": frames_per_launch}
 names = {"afstft_analysis_kernel": "afstft_analysis", "band_gemm_kernel": "band_gemm", "afstft_synthesis_kernel": "afstft_synthesis"}
 for k, short in names.items():
     if k not in acc:
