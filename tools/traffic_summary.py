@@ -9,7 +9,7 @@ import csv, glob, json, os, sys, collections
 
 READ_CORR = {   # kernel -> (factor, note)
     "band_gemm_kernel": (2.0, "16 B/lane loads: FETCH_SIZE x 2 (guide)"),
-    "afstft_synthesis_kernel": (2.0, "8 B/lane loads: x 2 (matches the algorithmic bytes; width not covered by the guide)"),
+    "afstft_synthesis_ws_kernel": (2.0, "8 B/lane loads: x 2 (matches the algorithmic bytes; width not covered by the guide)"),
     "afstft_analysis_kernel": (2.0, "4 B/lane loads, 256 B contiguous per wave: x 2 (face value would be below the input bytes alone)"),
 }
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -23,7 +23,7 @@ for d in args:
             k = row["Kernel_Name"].split("(")[0].split("<")[0].replace("saf::", "").replace("void ", "")
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"frames_per_launch": frames_per_launch}
-names = {"afstft_analysis_kernel": "afstft_analysis", "band_gemm_kernel": "band_gemm", "afstft_synthesis_kernel": "afstft_synthesis"}
+names = {"afstft_analysis_kernel": "afstft_analysis", "band_gemm_kernel": "band_gemm", "afstft_synthesis_ws_kernel": "afstft_synthesis"}
 for k, short in names.items():
     if k not in acc:
         continue
