@@ -106,11 +106,18 @@ template <bool INV> __device__ __forceinline__ void dft8(float2 (&v)[8])
 /* 128-point complex FFT of the sequence stored in one LDS slot (z[n] at floats 2n, 2n+1), in place, by the
  * 8 lanes j = 0..7 of one FFT group (all in one wave: LDS operations of a wave execute in order, so the
  * group needs no barrier).  twJ[p] = exp(-2 pi i j p / 128).  Result Z[k] at floats 2k, 2k+1. */
-template <bool INV, typename TW> __device__ __forceinline__ void fft128_slot(float* slot, int j, const TW& twJ)
+/* Slot addressing: complex element m of a slot lives at floats 2*(m ^ sg), 2*(m ^ sg) + 1, where sg = SLOT_SG(position of
+ * the slot) in 0..7.  The XOR only permutes elements inside groups of 8, so every access of the FFT (lane j <-> element
+ * j + 8m) stays conflict-free, while the "column" accesses of the split / pack phases — the same element of 16 consecutive
+ * slots, whose bases are only 16 banks apart — are spread over all banks instead of colliding 4- to 8-fold. */
+#define SLOT_SG(pos) (((pos) >> 1) & 7)
+
+template <bool INV, typename TW> __device__ __forceinline__ void fft128_slot(float* slot, int j, const TW& twJ, int sg)
 {
+    const int js = j ^ sg;
     float2 v[16];
 #pragma unroll
-    for (int m = 0; m < 16; m++) v[m] = *reinterpret_cast<const float2*>(slot + 2 * j + 16 * m);      /* z[j + 8m] */
+    for (int m = 0; m < 16; m++) v[m] = *reinterpret_cast<const float2*>(slot + 2 * js + 16 * m);      /* z[j + 8m] */
     dft16<INV>(v);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     /* transpose buffer T[p][j] at floats 16p + 2*(j ^ (p&7)) */
@@ -131,8 +138,8 @@ template <bool INV, typename TW> __device__ __forceinline__ void fft128_slot(flo
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        *reinterpret_cast<float2*>(slot + 2 * (j + 16 * q)) = X8(a, q);          /* Z[j + 16q] */
-        *reinterpret_cast<float2*>(slot + 2 * (j + 8 + 16 * q)) = X8(b, q);      /* Z[j + 8 + 16q] */
+        *reinterpret_cast<float2*>(slot + 2 * (js + 16 * q)) = X8(a, q);          /* Z[j + 16q] */
+        *reinterpret_cast<float2*>(slot + 2 * (js + 8 + 16 * q)) = X8(b, q);      /* Z[j + 8 + 16q] */
     }
 }
 
@@ -150,20 +157,20 @@ struct AnaArgs {
 
 /* bins k and 128-k (k = 0..64) of the 256-point real FFT from the packed 128-point spectrum in an LDS slot
  * (kiss_fftr.c:86-123 convention).  k = 0 gives X[0] and X[128] (Z[128] := Z[0], W256^0 = 1). */
-__device__ __forceinline__ void ana_bin_pair(const float* slot, int k, float2 W, float2& Xk, float2& Xm)
+__device__ __forceinline__ void ana_bin_pair(const float* slot, int sg, int k, float2 W, float2& Xk, float2& Xm)
 {
-    const float2 Zk = *reinterpret_cast<const float2*>(slot + 2 * k);
-    const float2 Zm = *reinterpret_cast<const float2*>(slot + 2 * ((128 - k) & 127));
+    const float2 Zk = *reinterpret_cast<const float2*>(slot + 2 * (k ^ sg));
+    const float2 Zm = *reinterpret_cast<const float2*>(slot + 2 * (((128 - k) & 127) ^ sg));
     const float2 e = make_float2(Zk.x + Zm.x, Zk.y - Zm.y);
     const float2 d = make_float2(Zk.x - Zm.x, Zk.y + Zm.y);
     const float2 t = cmul(W, d);
     Xk = make_float2(0.5f * (e.x + t.y), 0.5f * (e.y - t.x));
     Xm = make_float2(0.5f * (e.x - t.y), 0.5f * (-e.y - t.x));
 }
-__device__ __forceinline__ float2 ana_bin_lo(const float* slot, int k, float2 W)
+__device__ __forceinline__ float2 ana_bin_lo(const float* slot, int sg, int k, float2 W)
 {
     float2 a, b;
-    ana_bin_pair(slot, k, W, a, b);
+    ana_bin_pair(slot, sg, k, W, a, b);
     return a;
 }
 
@@ -246,10 +253,11 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
             if (k & 1) fo = fmaf(xv, w[k], fo); else fe = fmaf(xv, w[k], fe);
         }
         float* slot = s_ring + (fc * ARING + t) * SLOT;
-        slot[fn] = fe; slot[128 + fn] = fo;
+        const int fa = 2 * ((fn >> 1) ^ SLOT_SG(t)) + (fn & 1);
+        slot[fa] = fe; slot[128 + fa] = fo;
     }
     lds_barrier();
-    if (fftT < 6) fft128_slot<false>(s_ring + (fftC * ARING + fftT) * SLOT, fj, twJ);
+    if (fftT < 6) fft128_slot<false>(s_ring + (fftC * ARING + fftT) * SLOT, fj, twJ, SLOT_SG(fftT));
     /* (the barrier after the first fold below orders these spectra before their first use) */
 
     float2* outBase = g.a.out + (long long)inst * g.a.out_inst + (long long)chBase * g.a.out_ch;
@@ -269,7 +277,8 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
                 for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
                 int pos = p0 + t; if (pos >= ARING) pos -= ARING;
                 float* slot = s_ring + (fc * ARING + pos) * SLOT;
-                slot[fn] = fe; slot[128 + fn] = fo;
+                const int fa = 2 * ((fn >> 1) ^ SLOT_SG(pos)) + (fn & 1);
+                slot[fa] = fe; slot[128 + fa] = fo;
             }
         }
         /* the workgroup that owns the end of the launch records the new input history (the last 15 hops) from its window */
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
         /* 2. 256-point real FFT as a 128-point complex FFT of z[m] = f[2m] + i f[2m+1], in place in the slot */
         if (fftT < n) {
             int pos = p0 + fftT; if (pos >= ARING) pos -= ARING;
-            fft128_slot<false>(s_ring + (fftC * ARING + pos) * SLOT, fj, twJ);
+            fft128_slot<false>(s_ring + (fftC * ARING + pos) * SLOT, fj, twJ, SLOT_SG(pos));
         }
         lds_barrier();
         if (more) {
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
                 const float* ring = s_ring + c * ARING * SLOT;
                 const float2 W = s_tw256[k];
                 float2 Xk, Xm;
-                ana_bin_pair(ring + pD * SLOT, k, W, Xk, Xm);
+                ana_bin_pair(ring + pD * SLOT, SLOT_SG(pD), k, W, Xk, Xm);
                 const unsigned o = (unsigned)c * oc32 + ohop;
                 if (!g.a.hybrid) {
                     outBase[(unsigned)k * ob32 + o] = Xk;
@@ -331,10 +340,10 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
                         int p2 = pos - 2; if (p2 < 0) p2 += ARING;
                         int p4 = pos - 4; if (p4 < 0) p4 += ARING;
                         int p6 = pos - 6; if (p6 < 0) p6 += ARING;
-                        const float2 S0 = ana_bin_lo(ring + pos * SLOT, k, W);
-                        const float2 S2 = ana_bin_lo(ring + p2 * SLOT, k, W);
-                        const float2 S4 = ana_bin_lo(ring + p4 * SLOT, k, W);
-                        const float2 S6 = ana_bin_lo(ring + p6 * SLOT, k, W);
+                        const float2 S0 = ana_bin_lo(ring + pos * SLOT, SLOT_SG(pos), k, W);
+                        const float2 S2 = ana_bin_lo(ring + p2 * SLOT, SLOT_SG(p2), k, W);
+                        const float2 S4 = ana_bin_lo(ring + p4 * SLOT, SLOT_SG(p4), k, W);
+                        const float2 S6 = ana_bin_lo(ring + p6 * SLOT, SLOT_SG(p6), k, W);
                         float gr, gi;
                         gr = -COEFF1 * S0.y;          gi = COEFF1 * S0.x;
                         gr -= COEFF2 * S2.y;          gi += COEFF2 * S2.x;
@@ -450,15 +459,16 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
                     const float2 O = make_float2(D.x * W.x + D.y * W.y, D.y * W.x - D.x * W.y);      /* D * conj(W) */
                     if (gt < nn && kk <= 64) {
                         float* slot = ring + gt * SLOT;
-                        *reinterpret_cast<float2*>(slot + 2 * k) = make_float2(E.x - O.y, E.y + O.x);
-                        if (k != 0 && k != 64) *reinterpret_cast<float2*>(slot + 2 * (128 - k)) = make_float2(E.x + O.y, O.x - E.y);
+                        const int sg = SLOT_SG(gt);
+                        *reinterpret_cast<float2*>(slot + 2 * (k ^ sg)) = make_float2(E.x - O.y, E.y + O.x);
+                        if (k != 0 && k != 64) *reinterpret_cast<float2*>(slot + 2 * ((128 - k) ^ sg)) = make_float2(E.x + O.y, O.x - E.y);
                     }
                 }
             }
             lds_barrier();                                       /* (A) */
             /* 128-point inverse FFT in place: frame sample 2m, 2m+1 = Re, Im z[m] (x 1/256 in the overlap-add: 1/2 of the
              * packing above and the 1/128 of saf_rfft_backward's 1/N, saf_utility_fft.c:751) */
-            if (it >= 0 && it < nSub && ff < min(SUB, H - s0)) fft128_slot<true>(s_buf[it & 1] + ff * SLOT, fj, twJ);
+            if (it >= 0 && it < nSub && ff < min(SUB, H - s0)) fft128_slot<true>(s_buf[it & 1] + ff * SLOT, fj, twJ, SLOT_SG(ff));
             lds_barrier();                                       /* (B) */
         }
     } else {
@@ -492,7 +502,8 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
                     for (int u = 0; u < OLA; u++) {
                         if (u < nh) {
                             const float* slot = ring + (half * OLA + u) * SLOT;
-                            gl[9 + u] = slot[on] * sc; gr[9 + u] = slot[128 + on] * sc;
+                            const int oa = 2 * ((on >> 1) ^ SLOT_SG(half * OLA + u)) + (on & 1);
+                            gl[9 + u] = slot[oa] * sc; gr[9 + u] = slot[128 + oa] * sc;
                             float acc = 0.0f;
 #pragma unroll
                             for (int k = 9; k >= 0; k--) acc = fmaf(wn[k], (k & 1) ? gr[9 + u - k] : gl[9 + u - k], acc);
