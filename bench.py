@@ -88,8 +88,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--instances", type=int, default=int(os.environ.get("SAF_BENCH_INSTANCES", 64)), help="decoder instances per GPU")
-    ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("SAF_BENCH_FRAMES", 16)), help="consecutive blocks per instance per step")
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("SAF_BENCH_INSTANCES", 256)), help="decoder instances per GPU")
+    ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("SAF_BENCH_FRAMES", 64)), help="consecutive blocks per instance per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()

@@ -11,7 +11,7 @@ cp $(find $R/gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -1) $R/gpu
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/${TAG}_pmc_$C -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile > /dev/null 2> $R/gpurun_out/${TAG}_pmc_$C.err
 done
-python3 $R/tools/traffic_summary.py --frames-per-launch=1024 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE $R/gpurun_out/${TAG}_pmc_WRITE_SIZE > $R/gpurun_out/${TAG}_traffic.json
+python3 $R/tools/traffic_summary.py --frames-per-launch=16384 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE $R/gpurun_out/${TAG}_pmc_WRITE_SIZE > $R/gpurun_out/${TAG}_traffic.json
 cat $R/gpurun_out/${TAG}_traffic.json
 cd $R
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
