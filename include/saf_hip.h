@@ -433,6 +433,64 @@ SAF_API void saf_hip_powermap_analysis_dev(void* const hPm, const float* d_in, l
 SAF_API void saf_hip_powermap_getCx(void* const hPm, float_complex* Cx);
 SAF_API int  saf_hip_powermap_getRawPmap(void* const hPm, float* pmap);
 
+/* ========================================================================== */
+/*      panner (examples/include/panner.h:83-325) + getPvalues                 */
+/* ========================================================================== */
+#define PANNER_SPREAD_MIN_VALUE ( 0.0f )                                           /* panner.h:68 */
+#define PANNER_SPREAD_MAX_VALUE ( 90.0f )                                          /* panner.h:71 */
+SAF_API void getPvalues(float DTT, float* freq, int nFreq, float* pValues);        /* saf_vbap.h:292 */
+/** Replaces -DPANNER_FRAME_SIZE (panner_internal.h:67-73); call before panner_create. */
+SAF_API void saf_hip_panner_setFrameSize(int frameSize);
+SAF_API void panner_create(void** const phPan);                                    /* panner.h:83 */
+SAF_API void panner_destroy(void** const phPan);                                   /* panner.h:90 */
+SAF_API void panner_init(void* const hPan, int samplerate);                        /* panner.h:100 */
+SAF_API void panner_initCodec(void* const hPan);                                   /* panner.h:118 */
+SAF_API void panner_process(void* const hPan, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* panner.h:144 */
+SAF_API void panner_refreshSettings(void* const hPan);                             /* panner.h:160 */
+SAF_API void panner_setSourceAzi_deg(void* const hPan, int index, float newAzi_deg);   /* panner.h:163 */
+SAF_API void panner_setSourceElev_deg(void* const hPan, int index, float newElev_deg); /* panner.h:166 */
+SAF_API void panner_setNumSources(void* const hPan, int new_nSources);             /* panner.h:169 */
+SAF_API void panner_setLoudspeakerAzi_deg(void* const hPan, int index, float newAzi_deg);   /* panner.h:172 */
+SAF_API void panner_setLoudspeakerElev_deg(void* const hPan, int index, float newElev_deg); /* panner.h:175 */
+SAF_API void panner_setNumLoudspeakers(void* const hPan, int new_nLoudspeakers);   /* panner.h:178 */
+SAF_API void panner_setOutputConfigPreset(void* const hPan, int newPresetID);      /* panner.h:184 */
+SAF_API void panner_setInputConfigPreset(void* const hPan, int newPresetID);       /* panner.h:189 */
+SAF_API void panner_setDTT(void* const hPan, float newValue);                      /* panner.h:200 */
+SAF_API void panner_setSpread(void* const hPan, float newValue);                   /* panner.h:203 */
+SAF_API void panner_setYaw(void* const hPan, float newYaw);                        /* panner.h:206 */
+SAF_API void panner_setPitch(void* const hPan, float newPitch);                    /* panner.h:209 */
+SAF_API void panner_setRoll(void* const hPan, float newRoll);                      /* panner.h:212 */
+SAF_API void panner_setFlipYaw(void* const hPan, int newState);                    /* panner.h:218 */
+SAF_API void panner_setFlipPitch(void* const hPan, int newState);                  /* panner.h:224 */
+SAF_API void panner_setFlipRoll(void* const hPan, int newState);                   /* panner.h:230 */
+SAF_API int  panner_getFrameSize(void);                                            /* panner.h:241 */
+SAF_API CODEC_STATUS panner_getCodecStatus(void* const hPan);                      /* panner.h:244 */
+SAF_API float panner_getProgressBar0_1(void* const hPan);                          /* panner.h:251 */
+SAF_API void panner_getProgressBarText(void* const hPan, char* text);              /* panner.h:259 */
+SAF_API float panner_getSourceAzi_deg(void* const hPan, int index);                /* panner.h:262 */
+SAF_API float panner_getSourceElev_deg(void* const hPan, int index);               /* panner.h:265 */
+SAF_API int  panner_getNumSources(void* const hPan);                               /* panner.h:268 */
+SAF_API int  panner_getMaxNumSources(void);                                        /* panner.h:271 */
+SAF_API float panner_getLoudspeakerAzi_deg(void* const hPan, int index);           /* panner.h:274 */
+SAF_API float panner_getLoudspeakerElev_deg(void* const hPan, int index);          /* panner.h:277 */
+SAF_API int  panner_getNumLoudspeakers(void* const hPan);                          /* panner.h:280 */
+SAF_API int  panner_getMaxNumLoudspeakers(void);                                   /* panner.h:283 */
+SAF_API int  panner_getDAWsamplerate(void* const hPan);                            /* panner.h:286 */
+SAF_API float panner_getDTT(void* const hPan);                                     /* panner.h:289 */
+SAF_API float panner_getSpread(void* const hPan);                                  /* panner.h:292 */
+SAF_API float panner_getYaw(void* const hPan);                                     /* panner.h:295 */
+SAF_API float panner_getPitch(void* const hPan);                                   /* panner.h:298 */
+SAF_API float panner_getRoll(void* const hPan);                                    /* panner.h:301 */
+SAF_API int  panner_getFlipYaw(void* const hPan);                                  /* panner.h:307 */
+SAF_API int  panner_getFlipPitch(void* const hPan);                                /* panner.h:313 */
+SAF_API int  panner_getFlipRoll(void* const hPan);                                 /* panner.h:319 */
+SAF_API int  panner_getProcessingDelay(void);                                      /* panner.h:325 */
+/** Device-pointer entry: nFrames consecutive blocks, in[frame*in_frame_stride + ch*in_ch_stride + n] (same for out); enqueues only. */
+SAF_API void saf_hip_panner_process_dev(void* const hPan, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                        float* d_out, long long out_frame_stride, long long out_ch_stride, int nFrames);
+/** Read-back for parity checks: G_src as [133][64][64] (band, source, loudspeaker), panner_internal.h:99. */
+SAF_API void saf_hip_panner_getGains(void* const hPan, float* G);
+
 #ifdef __cplusplus
 }
 #endif

@@ -428,6 +428,46 @@ class Binauraliser:
             lib().orc_binauraliser_destroy(C.byref(self.h))
 
 
+# ------------------------------------------------------------------ panner
+class Panner:
+    def __init__(self, frameSize=128):
+        self.h = vp()
+        self.F = frameSize
+        L = lib()
+        L.orc_panner_create(C.byref(self.h), frameSize)
+        L.orc_panner_getGains.restype = c_f
+        L.orc_panner_getPvalue.restype = c_f
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_panner_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nOut, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.zeros((nOut, self.F), np.float32)
+        lib().orc_panner_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, ns)
+        return y
+
+    def gains(self):
+        """G_src [133][64][64] (band, source, loudspeaker)"""
+        return np.ctypeslib.as_array(lib().orc_panner_getGains(self.h), shape=(133, 64, 64)).copy()
+
+    def pvalues(self):
+        return np.ctypeslib.as_array(lib().orc_panner_getPvalue(self.h), shape=(133,)).copy()
+
+    def __del__(self):
+        if self.h:
+            lib().orc_panner_destroy(C.byref(self.h))
+
+
+def getPvalues(DTT, freq):
+    f = np.ascontiguousarray(freq, np.float32)
+    out = np.zeros(f.shape[0], np.float32)
+    lib().orc_getPvalues(C.c_float(DTT), fptr(f), f.shape[0], fptr(out))
+    return out
+
+
 # ------------------------------------------------------------------ powermap (PWD)
 class Powermap:
     def __init__(self, frameSize=1024):

@@ -179,6 +179,32 @@ const orc_cpx* orc_powermap_getCx(void* h);          /* [133][64*64], row stride
 const float* orc_powermap_getRawPmap(void* h);       /* [grid_nDirs] after temporal smoothing */
 int  orc_powermap_getGridNDirs(void* h);
 
+/* ---- panner (examples/src/panner) and getPvalues (saf_vbap.c:475-492) ---- */
+void orc_getPvalues(float DTT, const float* freq, int nFreq, float* pValues);
+void orc_panner_create(void** ph, int frameSize);
+void orc_panner_destroy(void** ph);
+void orc_panner_init(void* h, int sampleRate);
+void orc_panner_initCodec(void* h);
+void orc_panner_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
+void orc_panner_setSourceAzi_deg(void* h, int i, float v);
+void orc_panner_setSourceElev_deg(void* h, int i, float v);
+void orc_panner_setNumSources(void* h, int n);
+void orc_panner_setLoudspeakerAzi_deg(void* h, int i, float v);
+void orc_panner_setLoudspeakerElev_deg(void* h, int i, float v);
+void orc_panner_setNumLoudspeakers(void* h, int n);
+void orc_panner_setOutputConfigPreset(void* h, int id);
+void orc_panner_setInputConfigPreset(void* h, int id);
+void orc_panner_setDTT(void* h, float v);
+void orc_panner_setSpread(void* h, float v);
+void orc_panner_setYaw(void* h, float v);
+void orc_panner_setPitch(void* h, float v);
+void orc_panner_setRoll(void* h, float v);
+int  orc_panner_getNumSources(void* h);
+int  orc_panner_getNumLoudspeakers(void* h);
+int  orc_panner_getNTriangles(void* h);
+const float* orc_panner_getGains(void* h);      /* [133][64][64]: band, source, loudspeaker */
+const float* orc_panner_getPvalue(void* h);
+
 #ifdef __cplusplus
 }
 #endif

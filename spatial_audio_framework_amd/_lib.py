@@ -188,6 +188,32 @@ def load():
     sig("saf_hip_binauraliser_getWeights", None, vp, fp)
     sig("saf_hip_binauraliser_getHRTFfb", None, vp, vp)
     sig("saf_hip_binauraliser_getHRTFinterp", None, vp, vp)
+    # panner
+    sig("getPvalues", None, cf, fp, ci, fp)
+    sig("saf_hip_panner_setFrameSize", None, ci)
+    sig("panner_create", None, C.POINTER(vp))
+    sig("panner_destroy", None, C.POINTER(vp))
+    sig("panner_init", None, vp, ci)
+    sig("panner_initCodec", None, vp)
+    sig("panner_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("panner_refreshSettings", None, vp)
+    for n in ("setNumSources", "setNumLoudspeakers", "setOutputConfigPreset", "setInputConfigPreset", "setFlipYaw", "setFlipPitch", "setFlipRoll"):
+        sig("panner_" + n, None, vp, ci)
+    for n in ("setSourceAzi_deg", "setSourceElev_deg", "setLoudspeakerAzi_deg", "setLoudspeakerElev_deg"):
+        sig("panner_" + n, None, vp, ci, cf)
+    for n in ("setDTT", "setSpread", "setYaw", "setPitch", "setRoll"):
+        sig("panner_" + n, None, vp, cf)
+    for n in ("getFrameSize", "getMaxNumSources", "getMaxNumLoudspeakers", "getProcessingDelay"):
+        sig("panner_" + n, ci)
+    for n in ("getCodecStatus", "getNumSources", "getNumLoudspeakers", "getDAWsamplerate", "getFlipYaw", "getFlipPitch", "getFlipRoll"):
+        sig("panner_" + n, ci, vp)
+    for n in ("getProgressBar0_1", "getDTT", "getSpread", "getYaw", "getPitch", "getRoll"):
+        sig("panner_" + n, cf, vp)
+    for n in ("getSourceAzi_deg", "getSourceElev_deg", "getLoudspeakerAzi_deg", "getLoudspeakerElev_deg"):
+        sig("panner_" + n, cf, vp, ci)
+    sig("panner_getProgressBarText", None, vp, C.c_char_p)
+    sig("saf_hip_panner_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci)
+    sig("saf_hip_panner_getGains", None, vp, fp)
     # powermap
     sig("saf_hip_powermap_setFrameSize", None, ci)
     sig("powermap_create", None, C.POINTER(vp))

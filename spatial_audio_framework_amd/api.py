@@ -418,6 +418,48 @@ class Binauraliser:
             self.L.binauraliser_destroy(C.byref(self.h))
 
 
+# ---------------------------------------------------------------- panner
+class Panner:
+    """examples/include/panner.h.  `frameSize` plays the role of -DPANNER_FRAME_SIZE."""
+
+    def __init__(self, frameSize=128):
+        self.L = load()
+        self.L.saf_hip_panner_setFrameSize(frameSize)
+        self.h = vp()
+        self.F = frameSize
+        self.L.panner_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "panner_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nOut, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.panner_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def process_dev(self, d_in, in_strides, nIn, d_out, out_strides, nFrames):
+        """strides = (frame, ch) in floats."""
+        self.L.saf_hip_panner_process_dev(self.h, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nFrames)
+
+    def gains(self):
+        """G_src [133][64][64] (band, source, loudspeaker)"""
+        out = np.zeros((133, 64, 64), np.float32); self.L.saf_hip_panner_getGains(self.h, _f(out)); return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.panner_destroy(C.byref(self.h))
+
+
+def getPvalues(DTT, freq):
+    f = np.ascontiguousarray(freq, np.float32)
+    out = np.zeros(f.shape[0], np.float32)
+    load().getPvalues(C.c_float(DTT), _f(f), f.shape[0], _f(out))
+    return out
+
+
 # ---------------------------------------------------------------- powermap (PWD)
 class Powermap:
     """examples/include/powermap.h.  `frameSize` plays the role of -DPOWERMAP_FRAME_SIZE."""

@@ -202,6 +202,17 @@ struct BinMacLaunch {           /* out[band][ear][t] = scale * sum_src h[src][ba
 };
 void launch_binaural_mac(const BinMacLaunch& l);
 
+/* ---- panner gains (panner_kernels.hip) ---- */
+struct PanGainLaunch {          /* per moved source: table row -> per-band p-norm gains -> column `src` of A[band][ls][src] (panner.c:230-262) */
+    const float* gtable;        /* [nTable][nLS] */
+    const int* row;             /* [nSrc] table row of each source */
+    const int* recalc;          /* [nSrc] */
+    const float* pValue;        /* [133] */
+    float* A;                   /* [133][64][64] row = loudspeaker, column = source */
+    int nSrc, nLS;
+};
+void launch_panner_gains(const PanGainLaunch& l);
+
 /* ---- powermap kernels (powermap_kernels.hip) ---- */
 struct CovLaunch {              /* Cx[b] <- a Cx[b] + (1-a) X_f X_f^H for consecutive frames f (powermap.c:258-267) */
     const float2* X; long long x_band, x_ch;     /* spectra [band][ch][hop] */

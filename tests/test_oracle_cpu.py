@@ -403,3 +403,32 @@ def test_powermap_oracle_closed_forms(orc):
     assert m.min() == 0.0 and abs(m.max() - 1.0) < 1e-6
     r, c = np.unravel_index(m.argmax(), m.shape)
     assert abs(-180 + c * 360 / 140 - 60) < 5 and abs(-90 + r * 180 / 70 - 20) < 5
+
+
+def test_panner_closed_forms(orc):
+    """panner has no reference test (saf_vbap's test file is empty).  Closed forms: getPvalues at f = 0 is
+    2 - sqrt(DTT); DTT = 0 gives p = 2 everywhere and leaves the unit-energy VBAP gains untouched; a source on a
+    loudspeaker direction is routed to that loudspeaker alone; the output is the delayed, gain-weighted input."""
+    f = np.array([0.0, 1000.0, 24000.0], np.float32)
+    assert abs(orc.getPvalues(0.5, f)[0] - (2.0 - np.sqrt(0.5))) < 1e-6 and np.all(orc.getPvalues(0.0, f) == 2.0)
+    F = 128
+    p = orc.Panner(F)
+    p.setOutputConfigPreset(21)          # t-design, 24 loudspeakers
+    p.setInputConfigPreset(3)            # two sources (stereo pair directions)
+    p.initCodec(); p.init(48000); p.setDTT(0.0); p.initCodec()
+    ls = orc.table("Tdesign_degree_6_dirs_deg")
+    p.setSourceAzi_deg(0, float(round(ls[5, 0]))); p.setSourceElev_deg(0, float(round(ls[5, 1])))
+    x = frames(4, 2, 40 * F); x[1] = 0
+    y = np.concatenate([p.process(np.ascontiguousarray(x[:, i * F:(i + 1) * F]), 24) for i in range(40)], 1)
+    G = p.gains()
+    assert np.allclose((G[:, :2, :24] ** 2).sum(-1), 1.0, atol=1e-5)        # p = 2: energy-normalised VBAP gains
+    g0 = G[60, 0, :24]
+    assert g0.argmax() == 5 and g0[5] > 0.99                                 # nearest grid row to loudspeaker 5
+    d = 12 * 128
+    ref = np.outer(g0, x[0, :-d]) / np.sqrt(2.0)
+    assert relrms(y[:, d + 10 * F:], ref[:, 10 * F:]) < 2e-3                 # afSTFT is near-perfect reconstruction
+    # DTT = 1 (anechoic): low bands use p < 2, gains of a source between loudspeakers sum to more than the p = 2 ones
+    p.setDTT(1.0); p.initCodec(); p.setSourceAzi_deg(1, 10.0); p.process(np.zeros((2, F), np.float32), 24)
+    G1 = p.gains()[:, 1, :24]
+    pv = p.pvalues()
+    assert pv[0] == pytest.approx(1.0) and np.allclose((np.maximum(G1, 0) ** pv[:, None]).sum(-1) ** (1 / pv), 1.0, atol=1e-4)

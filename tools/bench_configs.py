@@ -159,6 +159,28 @@ def main():
                 "value": round(nI * nF / t, 1), "unit": "scene-frames/s", "batch": f"{nI} scenes x {nF} blocks per call", "kernels_ms": per,
                 "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": 2 * 64 * F * 4, "path_achieved_GBps": round(2 * 64 * F * 4 * nI * nF / t / 1e9, 1), "peak_GBps": HBM},
                 "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "scene-frames/s", "cores": 1, "kind": "port"}})
+
+    # ---- panner, 64 sources -> 64 loudspeakers (SphCovering-64), F = 512, 8 sources moved before every call
+    F, nS, nL, nF = 512, 64, 64, 64
+    def mkpan(cls):
+        pn = cls(F); pn.setOutputConfigPreset(29); pn.setInputConfigPreset(30); pn.initCodec(); pn.init(48000); return pn
+    gp = mkpan(api.Panner)
+    x = torch.rand(nS, nF * F, device="cuda") * 2 - 1; y = torch.zeros(nL, nF * F, device="cuda")
+    mv = [0]
+    def step_pan(pn=gp):
+        for k in range(8):
+            s = (mv[0] * 8 + k) % nS
+            pn.setSourceAzi_deg(s, float((37 * mv[0] + 11 * k) % 360 - 180)); pn.setSourceElev_deg(s, float((13 * mv[0] + 7 * k) % 120 - 60))
+        mv[0] += 1
+        gp.process_dev(x.data_ptr(), (F, nF * F), nS, y.data_ptr(), (F, nF * F), nF)
+    t, per = timed(L, torch, step_pan, steps, warm, ["afstft_analysis", "panner_gains", "band_gemm", "afstft_synthesis"])
+    op = mkpan(O.Panner); xb = frames(6, nS, F)
+    tc = cpu_time(lambda: op.process(xb, nL), 6.0)
+    out.append({"config": "panner (SURVEY 8f-1): 64 sources -> 64 loudspeakers (SphCovering-64), 512-sample blocks, 8 sources moved per call", "value": round(nF / t, 1), "unit": "frames/s",
+                "batch": f"1 handle x {nF} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": (nS + nL) * F * 4, "path_achieved_GBps": round((nS + nL) * F * 4 * nF / t / 1e9, 1), "peak_GBps": HBM,
+                             "note": "one handle = 64 analysis channels x 256 hops per call; same three kernels as ambi_dec plus the per-source gain kernel"},
+                "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s (static sources)", "cores": 1, "kind": "port"}})
     for o in out:
         print(json.dumps(o), flush=True)
 
