@@ -251,6 +251,15 @@ class AmbiDec:
         lib().orc_ambi_dec_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, x.shape[1])
         return y
 
+    def setHRIRs(self, hrirs, dirs_deg, fs):
+        hrirs = np.ascontiguousarray(hrirs, np.float32); d = np.ascontiguousarray(dirs_deg, np.float32)
+        lib().orc_ambi_dec_setHRIRs(self.h, fptr(hrirs), fptr(d), hrirs.shape[0], hrirs.shape[2], fs)
+
+    def hrtf_interp(self, nLS):
+        lib().orc_ambi_dec_getHRTFinterp.restype = vp
+        p = C.cast(lib().orc_ambi_dec_getHRTFinterp(self.h), C.POINTER(C.c_float))
+        return np.ctypeslib.as_array(p, shape=(64, 133, 2, 2)).copy().view(np.complex64)[:nLS, ..., 0]
+
     def decMtx(self, dec, order, maxrE, nLS):
         p = lib().orc_ambi_dec_getDecMtx(self.h, dec, order, maxrE)
         return np.ctypeslib.as_array(p, shape=(nLS, (order + 1) ** 2)).copy()

@@ -204,6 +204,29 @@ static void interp_hrtfs(orc_bin* p, int mode, float azi, float elev, orc_cpx* h
     }
 }
 
+/* ambi_dec_interpHRTFs (ambi_dec_internal.c:59-115): the magnitude + ITD interpolation (identical to INTERP_TRI_PS of
+ * binauraliser_interpHRTFs) on caller-held tables; 2 x 5 degree VBAP grid */
+void orc_interpHRTFs_ps(const float* gtableComp, const int* gtableIdx, const float* itds_s, const float* hrtf_fb_mag, int N,
+                        const float* freqVector, float azi, float elev, orc_cpx* hout /* [NB][2] */)
+{
+    const float aziRes = 2.0f, elevRes = 5.0f;
+    const int N_azi = (int)(360.0f / aziRes + 0.5f) + 1;
+    const int aziIndex = (int)(matlab_fmodf(azi + 180.0f, 360.0f) / aziRes + 0.5f);
+    const int elevIndex = (int)((elev + 90.0f) / elevRes + 0.5f);
+    const int idx3d = elevIndex * N_azi + aziIndex;
+    const float* w = &gtableComp[idx3d * 3]; const int* id = &gtableIdx[idx3d * 3];
+    float itd = 0.0f;
+    for (int i = 0; i < 3; i++) itd += w[i] * itds_s[id[i]];
+    for (int band = 0; band < NB; band++) {
+        float mag[2] = { 0, 0 };
+        for (int i = 0; i < 3; i++) for (int e = 0; e < 2; e++) mag[e] += w[i] * hrtf_fb_mag[((size_t)band * 2 + e) * N + id[i]];
+        const float ipd = freqVector[band] < 1.5e3f ? (matlab_fmodf(2.0f * ORC_PI * freqVector[band] * itd + ORC_PI, 2.0f * ORC_PI) - ORC_PI) / 2.0f : 0.0f;
+        const float c = cosf(ipd), s = sinf(ipd);
+        hout[band * 2 + 0].re = c * mag[0]; hout[band * 2 + 0].im = s * mag[0];
+        hout[band * 2 + 1].re = c * mag[1]; hout[band * 2 + 1].im = -s * mag[1];
+    }
+}
+
 static void rot_mtx(float yaw, float pitch, float roll, int rpy, float R[3][3])    /* yawPitchRoll2Rzyx (saf_utility_geometry.c:213-270) */
 {
     float Rx[3][3] = { { 1, 0, 0 }, { 0, cosf(roll), sinf(roll) }, { 0, -sinf(roll), cosf(roll) } };

@@ -62,6 +62,13 @@ typedef struct {
     float loudpkrs_dirs_deg[MAX_CH][2];
     int chOrdering, norm;
     double t_fwd, t_dec, t_bwd;
+    /* binauralised output (ambi_dec.c:349-445, 543-563); the HRIR set is injected (the reference's default set is absent) */
+    int binauraliseLS, new_binauraliseLS, enableHRIRsPreProc, reinit_hrtfs, recalc_hrtf[MAX_CH];
+    float* set_hrirs; float* set_dirs; int set_N, set_len, set_fs;
+    float* itds_s; float* weights; float* gtableComp; int* gtableIdx; orc_cpx* hrtf_fb; float* hrtf_fb_mag;
+    int N_hrir_dirs, N_gtable, hrtf_nTriangles;
+    orc_cpx* hrtf_interp;      /* [MAX_CH][NBANDS][2] */
+    orc_cpx* binframeTF;       /* [NBANDS][2][T] */
 } orc_ambi_dec;
 
 static void load_preset(int preset, float dirs[MAX_CH][2], int* nCH, int* nDims)
@@ -102,6 +109,10 @@ void orc_ambi_dec_create(void** ph, int frameSize)
     p->outputFrameTD = (float*)calloc((size_t)MAX_CH * p->F, sizeof(float));
     p->SHframeTF = (orc_cpx*)calloc((size_t)NBANDS * MAX_CH * p->T, sizeof(orc_cpx));
     p->outputframeTF = (orc_cpx*)calloc((size_t)NBANDS * MAX_CH * p->T, sizeof(orc_cpx));
+    p->enableHRIRsPreProc = 1; p->reinit_hrtfs = 1;
+    for (int ch = 0; ch < MAX_CH; ch++) p->recalc_hrtf[ch] = 1;
+    p->hrtf_interp = (orc_cpx*)calloc((size_t)MAX_CH * NBANDS * 2, sizeof(orc_cpx));
+    p->binframeTF = (orc_cpx*)calloc((size_t)NBANDS * 2 * p->T, sizeof(orc_cpx));
     *ph = p;
 }
 
@@ -111,6 +122,8 @@ void orc_ambi_dec_destroy(void** ph)
     if (!p) return;
     if (p->hSTFT) orc_afSTFT_destroy(&p->hSTFT);
     free(p->SHFrameTD); free(p->outputFrameTD); free(p->SHframeTF); free(p->outputframeTF);
+    free(p->set_hrirs); free(p->set_dirs); free(p->itds_s); free(p->weights); free(p->gtableComp); free(p->gtableIdx);
+    free(p->hrtf_fb); free(p->hrtf_fb_mag); free(p->hrtf_interp); free(p->binframeTF);
     for (int d = 0; d < NUM_DECODERS; d++) for (int n = 0; n < MAX_SH_ORDER; n++) { free(p->M_dec[d][n]); free(p->M_dec_maxrE[d][n]); }
     free(p); *ph = NULL;
 }
@@ -123,16 +136,17 @@ void orc_ambi_dec_init(void* h, int sampleRate)
     orc_afSTFT_getCentreFreqs(p->hSTFT, (float)sampleRate, NBANDS, p->freqVector);
 }
 
-/* ambi_dec_initCodec (ambi_dec.c:181-455), loudspeaker branch (HRIR branch :350-445 not restated) */
+/* ambi_dec_initCodec (ambi_dec.c:181-455) */
 void orc_ambi_dec_initCodec(void* h)
 {
     orc_ambi_dec* p = (orc_ambi_dec*)h;
     const int masterOrder = p->new_masterOrder;
     const int max_nSH = NSH(masterOrder);
     int nLS = p->new_nLoudpkrs;
-    if (!p->hSTFT) orc_afSTFT_create(&p->hSTFT, max_nSH, nLS, HOP, 0, 1, ORC_AFSTFT_BANDS_CH_TIME);
-    else orc_afSTFT_channelChange(p->hSTFT, max_nSH, nLS);
+    if (!p->hSTFT) orc_afSTFT_create(&p->hSTFT, max_nSH, p->new_binauraliseLS ? 2 : nLS, HOP, 0, 1, ORC_AFSTFT_BANDS_CH_TIME);
+    else orc_afSTFT_channelChange(p->hSTFT, max_nSH, p->new_binauraliseLS ? 2 : nLS);
     orc_afSTFT_clearBuffers(p->hSTFT);
+    p->binauraliseLS = p->new_binauraliseLS;
     p->nLoudpkrs = nLS;
     float sum_elev = 0.0f;
     for (int ch = 0; ch < nLS; ch++) sum_elev += fabsf(p->loudpkrs_dirs_deg[ch][1]);
@@ -190,10 +204,35 @@ void orc_ambi_dec_initCodec(void* h)
     }
     free(g);
     p->masterOrder = p->new_masterOrder;
+    /* binaural-related initialisations (ambi_dec.c:349-445); skipped while no HRIR set has been injected */
+    if (p->reinit_hrtfs && p->set_hrirs) {
+        const int N = p->set_N, len = p->set_len;
+        p->N_hrir_dirs = N;
+        p->itds_s = (float*)realloc(p->itds_s, sizeof(float) * N);
+        orc_estimateITDs(p->set_hrirs, N, len, p->set_fs, p->itds_s);
+        float* gtable = NULL;
+        orc_generateVBAPgainTable3D(p->set_dirs, N, 2, 5, 1, 0, 0.0f, &gtable, &p->N_gtable, &p->hrtf_nTriangles);
+        assert(gtable);
+        p->gtableComp = (float*)realloc(p->gtableComp, sizeof(float) * 3 * p->N_gtable);
+        p->gtableIdx = (int*)realloc(p->gtableIdx, sizeof(int) * 3 * p->N_gtable);
+        orc_compressVBAPgainTable3D(gtable, p->N_gtable, N, p->gtableComp, p->gtableIdx);
+        free(gtable);
+        p->hrtf_fb = (orc_cpx*)realloc(p->hrtf_fb, sizeof(orc_cpx) * (size_t)NBANDS * 2 * N);
+        orc_afSTFT_FIRtoFilterbankCoeffs(p->set_hrirs, N, 2, len, HOP, 0, 1, p->hrtf_fb);
+        if (p->enableHRIRsPreProc) {
+            p->weights = (float*)realloc(p->weights, sizeof(float) * N);
+            if (N <= 3600) orc_getVoronoiWeights(p->set_dirs, N, p->weights);
+            else for (int i = 0; i < N; i++) p->weights[i] = 4.f * ORC_PI / (float)N;
+            orc_diffuseFieldEqualiseHRTFs(N, NBANDS, p->weights, p->hrtf_fb);
+        }
+        p->hrtf_fb_mag = (float*)realloc(p->hrtf_fb_mag, sizeof(float) * (size_t)NBANDS * 2 * N);
+        for (size_t i = 0; i < (size_t)NBANDS * 2 * N; i++) p->hrtf_fb_mag[i] = hypotf(p->hrtf_fb[i].re, p->hrtf_fb[i].im);
+        p->reinit_hrtfs = 0;
+    }
     p->codecInitialised = 1;
 }
 
-/* ambi_dec_process (ambi_dec.c:457-580), binauraliseLS == 0 */
+/* ambi_dec_process (ambi_dec.c:457-580) */
 void orc_ambi_dec_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples)
 {
     orc_ambi_dec* p = (orc_ambi_dec*)h;
@@ -259,12 +298,34 @@ void orc_ambi_dec_process(void* h, const float* const* inputs, float* const* out
                 }
             }
         }
+        const int bin = p->binauraliseLS && p->hrtf_fb_mag;
+        if (bin) {      /* binauralise the loudspeaker signals (ambi_dec.c:543-563) */
+            memset(p->binframeTF, 0, sizeof(orc_cpx) * (size_t)NBANDS * 2 * T);
+            for (int ch = 0; ch < nLS; ch++) {
+                orc_cpx* hi = &p->hrtf_interp[(size_t)ch * NBANDS * 2];
+                if (p->recalc_hrtf[ch]) {
+                    orc_interpHRTFs_ps(p->gtableComp, p->gtableIdx, p->itds_s, p->hrtf_fb_mag, p->N_hrir_dirs, p->freqVector,
+                                       p->loudpkrs_dirs_deg[ch][0], p->loudpkrs_dirs_deg[ch][1], hi);
+                    p->recalc_hrtf[ch] = 0;
+                }
+                for (int band = 0; band < NBANDS; band++)
+                    for (int e = 0; e < 2; e++) {
+                        const orc_cpx a = hi[band * 2 + e];
+                        const orc_cpx* x = &p->outputframeTF[((size_t)band * MAX_CH + ch) * T];
+                        orc_cpx* y = &p->binframeTF[((size_t)band * 2 + e) * T];
+                        for (int t = 0; t < T; t++) { y[t].re += a.re * x[t].re - a.im * x[t].im; y[t].im += a.re * x[t].im + a.im * x[t].re; }
+                    }
+            }
+            const float sc = 1.0f / sqrtf((float)nLS);
+            for (size_t i = 0; i < (size_t)NBANDS * 2 * T; i++) { p->binframeTF[i].re *= sc; p->binframeTF[i].im *= sc; }
+        }
         double t2 = now_s();
-        orc_afSTFT_backward_knownDimensions(p->hSTFT, p->outputframeTF, F, MAX_CH, T, p->outputFrameTD);
+        orc_afSTFT_backward_knownDimensions(p->hSTFT, bin ? p->binframeTF : p->outputframeTF, F, bin ? 2 : MAX_CH, T, p->outputFrameTD);
         double t3 = now_s();
         p->t_fwd += t1 - t0; p->t_dec += t2 - t1; p->t_bwd += t3 - t2;
         int ch;
-        for (ch = 0; ch < (nLS < nOutputs ? nLS : nOutputs); ch++) memcpy(outputs[ch], &p->outputFrameTD[(size_t)ch * F], sizeof(float) * F);
+        const int nOutCh = bin ? 2 : nLS;
+        for (ch = 0; ch < (nOutCh < nOutputs ? nOutCh : nOutputs); ch++) memcpy(outputs[ch], &p->outputFrameTD[(size_t)ch * F], sizeof(float) * F);
         for (; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);
     } else
         for (int ch = 0; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);
@@ -282,7 +343,26 @@ void orc_ambi_dec_setLoudspeakers(void* h, const float* dirs_deg, int nLS)
     for (int i = 0; i < nLS; i++) { p->loudpkrs_dirs_deg[i][0] = dirs_deg[2 * i]; p->loudpkrs_dirs_deg[i][1] = dirs_deg[2 * i + 1]; }
     p->new_nLoudpkrs = nLS; p->codecInitialised = 0;
 }
-void orc_ambi_dec_setOutputConfigPreset(void* h, int id) { orc_ambi_dec* p = (orc_ambi_dec*)h; load_preset(id, p->loudpkrs_dirs_deg, &p->new_nLoudpkrs, &p->loudpkrs_nDims); p->codecInitialised = 0; }
+void orc_ambi_dec_setOutputConfigPreset(void* h, int id) { orc_ambi_dec* p = (orc_ambi_dec*)h; load_preset(id, p->loudpkrs_dirs_deg, &p->new_nLoudpkrs, &p->loudpkrs_nDims); p->codecInitialised = 0;
+    for (int ch = 0; ch < MAX_CH; ch++) p->recalc_hrtf[ch] = 1; }
+void orc_ambi_dec_setHRIRs(void* h, const float* hrirs, const float* dirs_deg, int N, int len, int fs)
+{
+    orc_ambi_dec* p = (orc_ambi_dec*)h;
+    free(p->set_hrirs); free(p->set_dirs);
+    p->set_hrirs = (float*)malloc(sizeof(float) * (size_t)N * 2 * len); memcpy(p->set_hrirs, hrirs, sizeof(float) * (size_t)N * 2 * len);
+    p->set_dirs = (float*)malloc(sizeof(float) * (size_t)N * 2); memcpy(p->set_dirs, dirs_deg, sizeof(float) * (size_t)N * 2);
+    p->set_N = N; p->set_len = len; p->set_fs = fs;
+    p->reinit_hrtfs = 1; p->codecInitialised = 0;
+    for (int ch = 0; ch < MAX_CH; ch++) p->recalc_hrtf[ch] = 1;
+}
+void orc_ambi_dec_setBinauraliseLSflag(void* h, int s) { orc_ambi_dec* p = (orc_ambi_dec*)h; p->new_binauraliseLS = s; if (p->new_binauraliseLS != p->binauraliseLS) p->codecInitialised = 0; }
+void orc_ambi_dec_setEnableHRIRsPreProc(void* h, int s) { orc_ambi_dec* p = (orc_ambi_dec*)h;
+    if (s != p->enableHRIRsPreProc) { p->enableHRIRsPreProc = s; p->reinit_hrtfs = 1; p->codecInitialised = 0; for (int ch = 0; ch < MAX_CH; ch++) p->recalc_hrtf[ch] = 1; } }
+void orc_ambi_dec_setLoudspeakerAzi_deg(void* h, int i, float v) { orc_ambi_dec* p = (orc_ambi_dec*)h; if (v > 180.0f) v = -360.0f + v; v = v < -180.0f ? -180.0f : (v > 180.0f ? 180.0f : v);
+    if (p->loudpkrs_dirs_deg[i][0] != v) { p->loudpkrs_dirs_deg[i][0] = v; p->recalc_hrtf[i] = 1; p->codecInitialised = 0; } }
+void orc_ambi_dec_setLoudspeakerElev_deg(void* h, int i, float v) { orc_ambi_dec* p = (orc_ambi_dec*)h; v = v < -90.0f ? -90.0f : (v > 90.0f ? 90.0f : v);
+    if (p->loudpkrs_dirs_deg[i][1] != v) { p->loudpkrs_dirs_deg[i][1] = v; p->recalc_hrtf[i] = 1; p->codecInitialised = 0; } }
+const orc_cpx* orc_ambi_dec_getHRTFinterp(void* h) { return ((orc_ambi_dec*)h)->hrtf_interp; }
 void orc_ambi_dec_setChOrder(void* h, int v) { orc_ambi_dec* p = (orc_ambi_dec*)h; if (v != 2 || p->new_masterOrder == 1) p->chOrdering = v; }
 void orc_ambi_dec_setNormType(void* h, int v) { orc_ambi_dec* p = (orc_ambi_dec*)h; if (v != 3 || p->new_masterOrder == 1) p->norm = v; }
 void orc_ambi_dec_setDecMethod(void* h, int index, int id) { orc_ambi_dec* p = (orc_ambi_dec*)h; p->dec_method[index] = id; p->codecInitialised = 0; }

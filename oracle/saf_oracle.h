@@ -92,6 +92,14 @@ void orc_ambi_dec_setDecOrder(void* h, int order, int band);
 void orc_ambi_dec_setDecOrderAllBands(void* h, int order);
 void orc_ambi_dec_setLoudspeakers(void* h, const float* dirs_deg, int nLS);
 void orc_ambi_dec_setOutputConfigPreset(void* h, int presetID);
+void orc_ambi_dec_setHRIRs(void* h, const float* hrirs, const float* dirs_deg, int N, int len, int fs);   /* stands in for the absent default set */
+void orc_ambi_dec_setBinauraliseLSflag(void* h, int s);
+void orc_ambi_dec_setEnableHRIRsPreProc(void* h, int s);
+void orc_ambi_dec_setLoudspeakerAzi_deg(void* h, int i, float v);
+void orc_ambi_dec_setLoudspeakerElev_deg(void* h, int i, float v);
+const orc_cpx* orc_ambi_dec_getHRTFinterp(void* h);     /* [64][133][2] */
+void orc_interpHRTFs_ps(const float* gtableComp, const int* gtableIdx, const float* itds_s, const float* hrtf_fb_mag, int N,
+                        const float* freqVector, float azi, float elev, orc_cpx* hout);
 void orc_ambi_dec_setChOrder(void* h, int newOrder);
 void orc_ambi_dec_setNormType(void* h, int newType);
 void orc_ambi_dec_setDecMethod(void* h, int index, int newID);

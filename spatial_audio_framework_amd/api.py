@@ -228,6 +228,11 @@ class AmbiDec:
         self.L.ambi_dec_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
         return y[:, :self.F]
 
+    def setHRIRs(self, hrirs, dirs_deg, fs):
+        """install the process-wide default HRIR set (what the reference links as saf_default_hrirs.c) and flag a re-init"""
+        setDefaultHRIRs(hrirs, dirs_deg, fs)
+        self.L.ambi_dec_refreshSettings(self.h)
+
     def decMtx(self, dec, order, maxrE, nLS):
         M = np.zeros((nLS, (order + 1) ** 2), np.float32)
         self.L.saf_hip_ambi_dec_getDecoderMtx(self.h, dec, order, maxrE, _f(M))

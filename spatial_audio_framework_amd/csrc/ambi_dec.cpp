@@ -17,6 +17,8 @@
 #include "afstft_state.h"
 #include "design_host.h"
 #include "presets.h"
+#include "hrtf_tables.h"
+#include "hrir_host.h"
 #include <thread>
 #include <chrono>
 
@@ -35,6 +37,7 @@ struct AmbiDec {
     float M_norm[NUM_DECODERS][SAF_MAX_ORDER][2];
     std::string sofa_filepath;
     int hrir_fs = 0;
+    std::shared_ptr<HrtfTables> hrtf;      /* itds, VBAP interpolation table, hrtf_fb(_mag) of ambi_dec_codecPars (ambi_dec_internal.h:100-118) */
     /* (ambi_dec_data, ambi_dec_internal.h:127-173) */
     float freqVector[SAF_NBANDS];
     int fs = 48000;
@@ -72,6 +75,19 @@ struct DecPipeline {
     DevBuf<int> band2mat;           /* [nInst][133] */
     DevBuf<float> chScale;          /* [nInst][64] */
     DevBuf<int> chMap;              /* [nInst][64] */
+    /* binauralised output (ambi_dec.c:543-563) */
+    bool bin = false;
+    std::shared_ptr<HrtfTables> hrtf;
+    DevBuf<float2> Z;               /* [nInst][133][2][Hmax] */
+    DevBuf<float2> hrtfInterp;      /* [nInst][64][133][2] */
+    DevBuf<float2> HM;              /* [nInst][64][133][2]  HRTFs x decoder: one 2 x nSH matrix per band */
+    DevBuf<float> Arow;             /* [nInst][NMAT][64][64] the decoder matrices, row-major, for the fold */
+    PinBuf<float> stageArow;
+    bool foldDirty = true;
+    DevBuf<float> lsDirs;           /* [nInst][64][2] */
+    DevBuf<float> freq;             /* [133] centre frequencies at the time of the last interpolation */
+    DevBuf<int> lsRecalc;           /* [nInst][64] */
+    PinBuf<float> stageD; PinBuf<int> stageR;
     /* host shadows to detect parameter changes between calls */
     struct Shadow {
         unsigned long long epoch = ~0ull;
@@ -94,13 +110,24 @@ struct DecPipeline {
             if (inst[i]->codecStatus != CODEC_STATUS_INITIALISED) SAF_FATAL("ambi_dec batch: instance %d is not initialised (call ambi_dec_initCodec)", i);
             if (ORDER2NSH(inst[i]->masterOrder) != nSH || inst[i]->nLoudpkrs != nLS)
                 SAF_FATAL("ambi_dec batch: all instances must share master order and loudspeaker count");
-            if (inst[i]->binauraliseLS) SAF_FATAL("ambi_dec batch: binauralised output is not implemented in this build");
+            if ((inst[i]->binauraliseLS != 0) != (inst[0]->binauraliseLS != 0)) SAF_FATAL("ambi_dec batch: all instances must agree on the binauraliseLS flag");
+            if (inst[i]->binauraliseLS && inst[i]->hrtf != inst[0]->hrtf) SAF_FATAL("ambi_dec batch: binauralising instances must share HRIR set, pre-processing flag and sample rate");
         }
-        st.create(nInst, nSH, nLS);
+        bin = inst[0]->binauraliseLS != 0;
+        st.create(nInst, nSH, bin ? 2 : nLS);
+        if (bin) {
+            hrtf = inst[0]->hrtf;
+            Z.alloc((size_t)nInst * SAF_NBANDS * 2 * Hmax, true);
+            hrtfInterp.alloc((size_t)nInst * SAF_MAXCH * SAF_NBANDS * 2); HM.alloc((size_t)nInst * SAF_MAXCH * SAF_NBANDS * 2);
+            Arow.alloc((size_t)nInst * NMAT * 64 * 64); stageArow.ensure((size_t)NMAT * 64 * 64);
+            lsDirs.alloc((size_t)nInst * SAF_MAXCH * 2); lsRecalc.alloc((size_t)nInst * SAF_MAXCH); freq.alloc(SAF_NBANDS);
+            stageD.ensure((size_t)nInst * SAF_MAXCH * 2 + SAF_NBANDS); stageR.ensure((size_t)nInst * SAF_MAXCH);
+            for (int i = 0; i < n; i++) for (int ch = 0; ch < SAF_MAXCH; ch++) inst[i]->recalc_hrtf_interpFLAG[ch] = 1;     /* a new pipeline starts without interpolated HRTFs */
+        }
         /* zeroed once: the analysis only ever writes the first nSH channel rows, the GEMM reads all 64
          * (against zero matrix columns) — stale NaNs there would poison the product */
         X.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);
-        Y.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);
+        if (!bin) Y.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);      /* binauralised output never forms the loudspeaker spectra */
         Afrag.alloc((size_t)nInst * NMAT * 64 * 64);
         band2mat.alloc((size_t)nInst * SAF_NBANDS);
         chScale.alloc((size_t)nInst * SAF_MAXCH);
@@ -133,8 +160,10 @@ struct DecPipeline {
                                 for (int k = 0; k < nSHo; k++) A[l * 64 + k] = M[(size_t)l * nSHo + k] * sc;
                         }
                         pack_A(A.data(), stageA.p + (size_t)(d * SAF_MAX_ORDER + n - 1) * 64 * 64);
+                        if (bin) memcpy(stageArow.p + (size_t)(d * SAF_MAX_ORDER + n - 1) * 64 * 64, A.data(), sizeof(float) * 64 * 64);
                     }
                 HIP_CHECK(hipMemcpyAsync(Afrag.p + (size_t)i * NMAT * 64 * 64, stageA.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream()));
+                if (bin) { HIP_CHECK(hipMemcpyAsync(Arow.p + (size_t)i * NMAT * 64 * 64, stageArow.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream())); foldDirty = true; }
                 HIP_CHECK(hipStreamSynchronize(stream()));
                 s.epoch = p->codecEpoch; s.rE[0] = rE[0]; s.rE[1] = rE[1]; s.eq[0] = eq[0]; s.eq[1] = eq[1];
                 s.b2mValid = false; s.norm = -1;
@@ -151,7 +180,7 @@ struct DecPipeline {
                 memcpy(stageI.p, b2m, sizeof(b2m));
                 HIP_CHECK(hipMemcpyAsync(band2mat.p + (size_t)i * SAF_NBANDS, stageI.p, sizeof(b2m), hipMemcpyHostToDevice, stream()));
                 HIP_CHECK(hipStreamSynchronize(stream()));
-                memcpy(s.b2m, b2m, sizeof(b2m)); s.b2mValid = true;
+                memcpy(s.b2m, b2m, sizeof(b2m)); s.b2mValid = true; foldDirty = true;
             }
             if (s.norm != (int)p->norm || s.chOrd != (int)p->chOrdering) {
                 /* input conventions -> ACN/N3D (ambi_dec.c:500-511, saf_hoa.c:40-116) as a gather map + row scale */
@@ -178,12 +207,50 @@ struct DecPipeline {
         }
     }
 
+    /* interpolated HRTFs of the loudspeakers whose direction changed (ambi_dec.c:549-553, ambi_dec_interpHRTFs =
+     * the magnitude + ITD mode of the binauraliser's interpolation kernel) */
+    void refresh_hrtfs()
+    {
+        bool any = false;
+        for (int i = 0; i < nInst && !any; i++) for (int ch = 0; ch < nLS; ch++) any = any || inst[i]->recalc_hrtf_interpFLAG[ch];
+        if (!any) return;
+        foldDirty = true;
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        for (int i = 0; i < nInst; i++)
+            for (int ch = 0; ch < SAF_MAXCH; ch++) {
+                stageD.p[((size_t)i * SAF_MAXCH + ch) * 2] = inst[i]->loudpkrs_dirs_deg[ch][0];
+                stageD.p[((size_t)i * SAF_MAXCH + ch) * 2 + 1] = inst[i]->loudpkrs_dirs_deg[ch][1];
+                stageR.p[(size_t)i * SAF_MAXCH + ch] = ch < nLS ? inst[i]->recalc_hrtf_interpFLAG[ch] : 0;
+                if (ch < nLS) inst[i]->recalc_hrtf_interpFLAG[ch] = 0;
+            }
+        memcpy(stageD.p + (size_t)nInst * SAF_MAXCH * 2, inst[0]->freqVector, sizeof(float) * SAF_NBANDS);       /* ambi_dec_internal.c:106-108 reads pData->freqVector */
+        HIP_CHECK(hipMemcpyAsync(lsDirs.p, stageD.p, sizeof(float) * (size_t)nInst * SAF_MAXCH * 2, hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(freq.p, stageD.p + (size_t)nInst * SAF_MAXCH * 2, sizeof(float) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(lsRecalc.p, stageR.p, sizeof(int) * (size_t)nInst * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
+        HrtfInterpLaunch l{};
+        l.srcDirs = lsDirs.p; l.recalc = lsRecalc.p; l.gtComp = hrtf->d_gtComp.p; l.gtIdx = hrtf->d_gtIdx.p;
+        l.hrtf_fb = hrtf->d_hrtf_fb.p; l.hrtf_mag = hrtf->d_mag.p; l.itds = hrtf->d_itds.p; l.freq = freq.p;
+        l.hrtf_interp = hrtfInterp.p; l.nSrc = nLS; l.N = hrtf->N; l.mode = 2 /* INTERP_TRI_PS */;
+        l.aziRes = hrtf->vbapTableRes[0]; l.elevRes = hrtf->vbapTableRes[1];
+        l.nInst = nInst; l.srcStride = SAF_MAXCH;
+        launch_hrtf_interp(l);
+    }
+
     void process(const float* d_in, long long in_inst, long long in_frame, long long in_ch, int nChPresent,
                  float* d_out, long long out_inst, long long out_frame, long long out_ch, int nFrames)
     {
         if (nFrames <= 0) return;
         if (nFrames > maxFrames) SAF_FATAL("ambi_dec batch: nFrames %d exceeds the maxFramesPerCall %d given at creation", nFrames, maxFrames);
         refresh();
+        if (bin) {
+            refresh_hrtfs();
+            if (foldDirty) {
+                BinFoldLaunch f{};
+                f.h = hrtfInterp.p; f.A = Arow.p; f.band2mat = band2mat.p; f.HM = HM.p; f.nInst = nInst; f.nMat = NMAT; f.nLS = nLS;
+                launch_binaural_fold(f);
+                foldDirty = false;
+            }
+        }
         const int H = nFrames * T;
         AnaLaunch a{};
         a.in = d_in; a.in_inst = in_inst; a.in_ch = in_ch; a.in_frame = in_frame; a.hopsPerFrame = T; a.nChIn = nChPresent;
@@ -195,18 +262,33 @@ struct DecPipeline {
         launch_analysis(a);
         st.anaPar ^= 1;
 
-        BandGemmLaunch g{};
-        g.X = (const float*)X.p; g.x_inst = 2 * a.out_inst; g.x_band = 2 * a.out_band; g.x_row = 2 * a.out_ch;
-        g.Y = (float*)Y.p; g.y_inst = g.x_inst; g.y_band = g.x_band; g.y_row = g.x_row;
-        g.Afrag = Afrag.p; g.a_inst = (long long)NMAT * 64 * 64; g.band2mat = band2mat.p;
-        g.nBands = SAF_NBANDS; g.nInst = nInst; g.N = 2 * H;
-        launch_band_gemm(g);
+        if (!bin) {
+            BandGemmLaunch g{};
+            g.X = (const float*)X.p; g.x_inst = 2 * a.out_inst; g.x_band = 2 * a.out_band; g.x_row = 2 * a.out_ch;
+            g.Y = (float*)Y.p; g.y_inst = g.x_inst; g.y_band = g.x_band; g.y_row = g.x_row;
+            g.Afrag = Afrag.p; g.a_inst = (long long)NMAT * 64 * 64; g.band2mat = band2mat.p;
+            g.nBands = SAF_NBANDS; g.nInst = nInst; g.N = 2 * H;
+            launch_band_gemm(g);
+        }
 
         SynLaunch s{};
         s.in = Y.p; s.in_inst = a.out_inst; s.in_band = a.out_band; s.in_ch = a.out_ch;
+        s.nCh = nLS;
+        if (bin) {
+            /* decode + binauralise (ambi_dec.c:518-563) as ONE band MAC: ears = (H_b M_b) x_b / sqrt(nLS).  The reference
+             * forms the loudspeaker spectra M_b x_b first and then applies the HRTFs; both steps are linear, so the
+             * 2 x nSH product matrix gives the same ears without materialising 64 loudspeaker channels. */
+            BinMacLaunch m{};
+            m.X = X.p; m.x_inst = a.out_inst; m.x_band = a.out_band; m.x_ch = a.out_ch;
+            m.h = HM.p; m.h_inst = (long long)SAF_MAXCH * SAF_NBANDS * 2;
+            m.Y = Z.p; m.y_inst = (long long)SAF_NBANDS * 2 * Hmax; m.y_band = (long long)2 * Hmax; m.y_ch = Hmax;
+            m.nSrc = nSH; m.H = H; m.scale = 1.0f / sqrtf((float)nLS); m.nInst = nInst;
+            launch_binaural_mac(m);
+            s.in = Z.p; s.in_inst = m.y_inst; s.in_band = m.y_band; s.in_ch = m.y_ch; s.nCh = 2;
+        }
         s.out = d_out; s.out_inst = out_inst; s.out_ch = out_ch; s.out_frame = out_frame; s.hopsPerFrame = T;
         s.hist_rd = st.syn[st.synPar].p; s.hist_wr = st.syn[st.synPar ^ 1].p;
-        s.nCh = nLS; s.nInst = nInst; s.H = H; s.lowDelay = 0; s.hybrid = 1;
+        s.nInst = nInst; s.H = H; s.lowDelay = 0; s.hybrid = 1;
         launch_synthesis(s);
         st.synPar ^= 1;
     }
@@ -359,9 +441,18 @@ void ambi_dec_initCodec(void* const hAmbi)
     }
     p->masterOrder = p->new_masterOrder;
 
-    /* HRIR branch (ambi_dec.c:350-445): needs the default HRIR set, which neither the reference
-     * checkout (.MISSING_LARGE_BLOBS) nor this build ships; binauralised output is "next" (SURVEY §8f-2). */
-    p->reinit_hrtfsFLAG = 0;
+    /* Binaural-related initialisations (ambi_dec.c:349-445).  The reference runs them on every re-init whether or not the
+     * output is binauralised; its default HRIR set is not part of the checkout, so here they run when binauralised output
+     * is requested (and abort with a message when no set has been installed with saf_hip_setDefaultHRIRs). */
+    if (p->binauraliseLS && (p->reinit_hrtfsFLAG || !p->hrtf || p->hrtf->hrirEpoch != default_hrirs().epoch)) {
+        strcpy(p->progressBarText, "Computing VBAP gain table");
+        p->progressBar0_1 = 0.4f;
+        p->useDefaultHRIRsFLAG = 1;                         /* "can only load the default HRIR data" (ambi_dec.c:381) */
+        p->hrtf = ambi_dec_hrtf_tables(p->freqVector, p->enableHRIRsPreProc);
+        p->hrir_fs = p->hrtf->fs;
+        for (int ch = 0; ch < SAF_MAXCH; ch++) p->recalc_hrtf_interpFLAG[ch] = 1;
+        p->reinit_hrtfsFLAG = 0;
+    }
 
     p->codecEpoch++;
     strcpy(p->progressBarText, "Done!");
@@ -373,7 +464,7 @@ void ambi_dec_process(void* const hAmbi, const float* const* inputs, float** con
 {
     AmbiDec* p = (AmbiDec*)hAmbi;
     const int F = p->F;
-    if (nSamples == F && p->codecStatus == CODEC_STATUS_INITIALISED && !p->binauraliseLS) {
+    if (nSamples == F && p->codecStatus == CODEC_STATUS_INITIALISED) {
         p->procStatus = PROC_STATUS_ONGOING;
         const int nSH = ORDER2NSH(p->masterOrder), nLS = p->nLoudpkrs;
         if (!p->pipe) {
@@ -391,10 +482,11 @@ void ambi_dec_process(void* const hAmbi, const float* const* inputs, float** con
         const int nRows = (nSH < 4 ? 4 : nSH);
         HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nRows * F, hipMemcpyHostToDevice, stream()));
         p->pipe->process(p->d_in.p, 0, 0, F, nRows, p->d_out.p, 0, 0, F, 1);
-        HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nLS * F, hipMemcpyDeviceToHost, stream()));
+        const int nOutCh = p->binauraliseLS ? 2 : nLS;                     /* NUM_EARS or the loudspeakers (ambi_dec.c:570) */
+        HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nOutCh * F, hipMemcpyDeviceToHost, stream()));
         HIP_CHECK(hipStreamSynchronize(stream()));
         int ch;
-        for (ch = 0; ch < (nLS < nOutputs ? nLS : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);
+        for (ch = 0; ch < (nOutCh < nOutputs ? nOutCh : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);
         for (; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);
     } else
         for (int ch = 0; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);      /* ambi_dec.c:575-577 */

@@ -20,7 +20,7 @@ struct InterpArgs { HrtfInterpLaunch l; };
 __global__ __launch_bounds__(192) void hrtf_interp_kernel(InterpArgs a)
 {
     const HrtfInterpLaunch& l = a.l;
-    const int src = blockIdx.x, band = threadIdx.x;
+    const int src = blockIdx.y * l.srcStride + blockIdx.x, band = threadIdx.x;
     if (!l.recalc[src] || band >= SAF_NBANDS) return;
     const float azi = l.srcDirs[src * 2], elev = l.srcDirs[src * 2 + 1];
     const float aziRes = (float)l.aziRes, elevRes = (float)l.elevRes;
@@ -64,13 +64,13 @@ void launch_hrtf_interp(const HrtfInterpLaunch& l)
     if (l.nSrc <= 0) return;
     InterpArgs a; a.l = l;
     KernelTimer kt("hrtf_interp");
-    hipLaunchKernelGGL(hrtf_interp_kernel, dim3(l.nSrc), dim3(192), 0, stream(), a);
+    hipLaunchKernelGGL(hrtf_interp_kernel, dim3(l.nSrc, l.nInst > 0 ? l.nInst : 1), dim3(192), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 
 struct MacArgs2 { BinMacLaunch l; int TT, logTT; };
 
-/* grid (ceil(H / TT), 133); 256 threads = TT hops x (256 / TT) source groups */
+/* grid (ceil(H / TT), 133, nInst); 256 threads = TT hops x (256 / TT) source groups */
 __global__ __launch_bounds__(256) void binaural_mac_kernel(MacArgs2 a)
 {
     __shared__ float2 s_red[256][2];
@@ -81,10 +81,11 @@ __global__ __launch_bounds__(256) void binaural_mac_kernel(MacArgs2 a)
     const int hop = blockIdx.x * a.TT + t;
     float2 accL = make_float2(0.f, 0.f), accR = make_float2(0.f, 0.f);
     if (hop < l.H) {
-        const float2* X = l.X + (long long)band * l.x_band + hop;
+        const float2* X = l.X + (long long)blockIdx.z * l.x_inst + (long long)band * l.x_band + hop;
+        const float2* hh = l.h + (long long)blockIdx.z * l.h_inst;
         for (int src = sg; src < l.nSrc; src += nG) {
             const float2 x = X[(long long)src * l.x_ch];
-            const float2 hl = l.h[((long long)src * SAF_NBANDS + band) * 2], hr = l.h[((long long)src * SAF_NBANDS + band) * 2 + 1];
+            const float2 hl = hh[((long long)src * SAF_NBANDS + band) * 2], hr = hh[((long long)src * SAF_NBANDS + band) * 2 + 1];
             accL.x = fmaf(hl.x, x.x, accL.x); accL.x = fmaf(-hl.y, x.y, accL.x);
             accL.y = fmaf(hl.x, x.y, accL.y); accL.y = fmaf(hl.y, x.x, accL.y);
             accR.x = fmaf(hr.x, x.x, accR.x); accR.x = fmaf(-hr.y, x.y, accR.x);
@@ -105,9 +106,36 @@ __global__ __launch_bounds__(256) void binaural_mac_kernel(MacArgs2 a)
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float2 v = s_red[tid][e];
-            l.Y[(long long)band * l.y_band + (long long)e * l.y_ch + hop] = make_float2(v.x * l.scale, v.y * l.scale);     /* cblas_sscal 1/sqrt(nSources) */
+            l.Y[(long long)blockIdx.z * l.y_inst + (long long)band * l.y_band + (long long)e * l.y_ch + hop] = make_float2(v.x * l.scale, v.y * l.scale);     /* cblas_sscal 1/sqrt(nSources) */
         }
     }
+}
+
+/* grid (133, nInst); 128 threads = (SH channel, ear).  Runs only when a decoder matrix, the band -> matrix map or an
+ * interpolated HRTF changed. */
+struct FoldArgs { BinFoldLaunch l; };
+__global__ __launch_bounds__(128) void binaural_fold_kernel(FoldArgs a)
+{
+    const BinFoldLaunch& l = a.l;
+    const int band = blockIdx.x, inst = blockIdx.y;
+    const int sh = threadIdx.x >> 1, ear = threadIdx.x & 1;
+    const float* A = l.A + ((long long)inst * l.nMat + l.band2mat[inst * SAF_NBANDS + band]) * 64 * 64;
+    const float2* h = l.h + (long long)inst * SAF_MAXCH * SAF_NBANDS * 2;
+    float re = 0.0f, im = 0.0f;
+    for (int ls = 0; ls < l.nLS; ls++) {
+        const float2 hv = h[((long long)ls * SAF_NBANDS + band) * 2 + ear];
+        const float m = A[ls * 64 + sh];
+        re = fmaf(hv.x, m, re); im = fmaf(hv.y, m, im);
+    }
+    l.HM[(long long)inst * SAF_MAXCH * SAF_NBANDS * 2 + ((long long)sh * SAF_NBANDS + band) * 2 + ear] = make_float2(re, im);
+}
+void launch_binaural_fold(const BinFoldLaunch& l)
+{
+    if (l.nInst <= 0) return;
+    FoldArgs a; a.l = l;
+    KernelTimer kt("binaural_fold");
+    hipLaunchKernelGGL(binaural_fold_kernel, dim3(SAF_NBANDS, l.nInst), dim3(128), 0, stream(), a);
+    HIP_CHECK(hipGetLastError());
 }
 
 void launch_binaural_mac(const BinMacLaunch& l)
@@ -118,7 +146,7 @@ void launch_binaural_mac(const BinMacLaunch& l)
     while (TT < l.H && TT < 64) { TT <<= 1; lg++; }
     a.TT = TT; a.logTT = lg;
     KernelTimer kt("binaural_mac");
-    hipLaunchKernelGGL(binaural_mac_kernel, dim3((l.H + TT - 1) / TT, SAF_NBANDS), dim3(256), 0, stream(), a);
+    hipLaunchKernelGGL(binaural_mac_kernel, dim3((l.H + TT - 1) / TT, SAF_NBANDS, l.nInst > 0 ? l.nInst : 1), dim3(256), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -111,6 +111,10 @@ extern "C" {
 void saf_hip_setDefaultHRIRs(const float* hrirs, const float* hrir_dirs_deg, int N_hrir_dirs, int hrir_len, int hrir_fs)
 {
     if (N_hrir_dirs < 4 || hrir_len < 1) SAF_FATAL("saf_hip_setDefaultHRIRs: need at least 4 directions and 1 tap");
+    /* installing the set that is already installed changes nothing (tables derived from it stay valid and shared) */
+    if (g_default.N == N_hrir_dirs && g_default.len == hrir_len && g_default.fs == hrir_fs &&
+        memcmp(g_default.hrirs.data(), hrirs, sizeof(float) * (size_t)N_hrir_dirs * 2 * hrir_len) == 0 &&
+        memcmp(g_default.dirs_deg.data(), hrir_dirs_deg, sizeof(float) * (size_t)N_hrir_dirs * 2) == 0) return;
     g_default.hrirs.assign(hrirs, hrirs + (size_t)N_hrir_dirs * 2 * hrir_len);
     g_default.dirs_deg.assign(hrir_dirs_deg, hrir_dirs_deg + (size_t)N_hrir_dirs * 2);
     g_default.N = N_hrir_dirs; g_default.len = hrir_len; g_default.fs = hrir_fs;

@@ -192,6 +192,7 @@ struct HrtfInterpLaunch {       /* binauraliser_interpHRTFs (binauraliser_intern
     const float* freq;          /* [133] */
     float2* hrtf_interp;        /* [nSrc][133][2] */
     int nSrc, N, mode, aziRes, elevRes;
+    int nInst = 1, srcStride = 0;   /* batches: instance i uses srcDirs / recalc / hrtf_interp entries i*srcStride + src */
 };
 void launch_hrtf_interp(const HrtfInterpLaunch& l);
 struct BinMacLaunch {           /* out[band][ear][t] = scale * sum_src h[src][band][ear] * X[band][src][t]  (binauraliser.c:252-268) */
@@ -199,8 +200,17 @@ struct BinMacLaunch {           /* out[band][ear][t] = scale * sum_src h[src][ba
     const float2* h;
     float2* Y; long long y_band, y_ch;
     int nSrc, H; float scale;
+    int nInst = 1; long long x_inst = 0, y_inst = 0, h_inst = 0;    /* batches: per-instance strides in float2 elements */
 };
 void launch_binaural_mac(const BinMacLaunch& l);
+struct BinFoldLaunch {          /* HM[inst][sh][band][ear] = sum_ls h[inst][ls][band][ear] * A[inst][band2mat[band]][ls][sh]: decoder and HRTFs as ONE 2 x nSH matrix per band */
+    const float2* h;            /* [nInst][64][133][2] */
+    const float* A;             /* [nInst][nMat][64][64] row-major [ls][sh] */
+    const int* band2mat;        /* [nInst][133] */
+    float2* HM;                 /* [nInst][64][133][2] */
+    int nInst, nMat, nLS;
+};
+void launch_binaural_fold(const BinFoldLaunch& l);
 
 /* ---- panner gains (panner_kernels.hip) ---- */
 struct PanGainLaunch {          /* per moved source: table row -> per-band p-norm gains -> column `src` of A[band][ls][src] (panner.c:230-262) */

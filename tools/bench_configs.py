@@ -181,6 +181,23 @@ def main():
                 "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": (nS + nL) * F * 4, "path_achieved_GBps": round((nS + nL) * F * 4 * nF / t / 1e9, 1), "peak_GBps": HBM,
                              "note": "one handle = 64 analysis channels x 256 hops per call; same three kernels as ambi_dec plus the per-source gain kernel"},
                 "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s (static sources)", "cores": 1, "kind": "port"}})
+
+    # ---- ambi_dec order 7 -> 64 virtual loudspeakers -> 2 ears (binauraliseLS), F = 512
+    F, nI, nF = 512, 64, 64
+    def mkdb(cls):
+        dd = cls(F); dd.setHRIRs(h, d, 48000); dd.setNormType(1); dd.setChOrder(1); dd.setMasterDecOrder(7); dd.setOutputConfigPreset(29)
+        dd.setDecMethod(0, 1); dd.setDecMethod(1, 1); dd.setBinauraliseLSflag(1); dd.init(48000); dd.initCodec(); dd.setDecOrderAllBands(7); return dd
+    gd = [mkdb(api.AmbiDec) for _ in range(nI)]
+    db = api.AmbiDecBatch(gd, nF)
+    x = torch.rand(nI, nF, 64, F, device="cuda") * 2 - 1; ears = torch.zeros(nI, nF, 2, F, device="cuda")
+    t, per = timed(L, torch, lambda: db.process_ptr(x.data_ptr(), (nF * 64 * F, 64 * F, F), ears.data_ptr(), (nF * 2 * F, 2 * F, F), nF), steps, warm,
+                   ["afstft_analysis", "band_gemm", "binaural_mac", "afstft_synthesis"])
+    od = mkdb(O.AmbiDec); xb = frames(7, 64, F)
+    tc = cpu_time(lambda: od.process(xb, 2), 6.0)
+    out.append({"config": "ambi_dec binauralised (SURVEY 8f-2): order 7 -> 64 virtual loudspeakers (SphCovering-64) -> 2 ears, 512-sample blocks, synthetic HRIR set", "value": round(nI * nF / t, 1), "unit": "frames/s",
+                "batch": f"{nI} instances x {nF} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": (64 + 2) * F * 4, "path_achieved_GBps": round((64 + 2) * F * 4 * nI * nF / t / 1e9, 1), "peak_GBps": HBM},
+                "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s", "cores": 1, "kind": "port"}})
     for o in out:
         print(json.dumps(o), flush=True)
 
