@@ -290,6 +290,24 @@ SAF_API void saf_hip_matrixConv_setMaxBlocksPerCall(int nBlocks);
 SAF_API void saf_hip_matrixConv_apply_dev(void* const hMC, const float* d_in, long long in_ch_stride, long long in_block_stride,
                                           float* d_out, long long out_ch_stride, long long out_block_stride, int nBlocks);
 
+/* Multi-channel convolver: channel c is filtered by H[c] (saf_utility_matrixConv.h:109-137 / .c:257-416).
+ *   H: nCH x length_h;  inputSig / outputSig: nCH x hopSize */
+SAF_API void saf_multiConv_create(void** const phMC, int hopSize, float* H, int length_h, int nCH, int usePartFLAG);   /* saf_utility_matrixConv.h:109 */
+SAF_API void saf_multiConv_destroy(void** const phMC);                                                                /* saf_utility_matrixConv.h:122 */
+SAF_API void saf_multiConv_apply(void* const hMC, float* inputSig, float* outputSig);                                 /* saf_utility_matrixConv.h:132 */
+SAF_API void saf_hip_multiConv_apply_dev(void* const hMC, const float* d_in, long long in_ch_stride, long long in_block_stride,
+                                         float* d_out, long long out_ch_stride, long long out_block_stride, int nBlocks);
+
+/* Time-varying convolver: one input, nCHout outputs, nIRs filter sets selected per block by irIdx with a linear
+ * cross-fade one block later (saf_utility_matrixConv.h:157-200 / .c:438-620).
+ *   H: nIRs pointers to FLAT(nCHout x length_h);  inputSig: hopSize;  outputSig: nCHout x hopSize */
+SAF_API void saf_TVConv_create(void** const phTVC, int hopSize, float** H, int length_h, int nIRs, int nCHout, int initIdx);   /* saf_utility_matrixConv.h:157 */
+SAF_API void saf_TVConv_destroy(void** const phTVC);                                                                          /* saf_utility_matrixConv.h:171 */
+SAF_API void saf_TVConv_apply(void* const hTVC, float* inputSig, float* outputSig, int irIdx);                                /* saf_utility_matrixConv.h:185 */
+/** nBlocks consecutive blocks of device-resident samples; irIdx is a HOST array of nBlocks indices. */
+SAF_API void saf_hip_TVConv_apply_dev(void* const hTVC, const float* d_in, long long in_block_stride,
+                                      float* d_out, long long out_ch_stride, long long out_block_stride, const int* irIdx, int nBlocks);
+
 /* ========================================================================== */
 /*      HRIR processing (saf_hrir.h) and Voronoi weights (saf_utility_geometry.h) */
 /* ========================================================================== */

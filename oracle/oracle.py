@@ -320,6 +320,44 @@ class MatrixConv:
             lib().orc_matrixConv_destroy(C.byref(self.h))
 
 
+class MultiConv:
+    def __init__(self, hop, H, part=1):
+        H = np.ascontiguousarray(H, np.float32)
+        self.nCH, self.L = H.shape
+        self.hop = hop
+        self.h = vp()
+        lib().orc_multiConv_create(C.byref(self.h), hop, fptr(H), self.L, self.nCH, part)
+
+    def apply(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((self.nCH, self.hop), np.float32)
+        lib().orc_multiConv_apply(self.h, fptr(x), fptr(y))
+        return y
+
+    def __del__(self):
+        if self.h:
+            lib().orc_multiConv_destroy(C.byref(self.h))
+
+
+class TVConv:
+    def __init__(self, hop, H, initIdx=0):
+        H = np.ascontiguousarray(H, np.float32)          # [nIRs][nCHout][L]
+        self.nIRs, self.nOut, self.L = H.shape
+        self.hop = hop
+        self.h = vp()
+        lib().orc_TVConv_create(C.byref(self.h), hop, fptr(H), self.L, self.nIRs, self.nOut, initIdx)
+
+    def apply(self, x, irIdx):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((self.nOut, self.hop), np.float32)
+        lib().orc_TVConv_apply(self.h, fptr(x), fptr(y), int(irIdx))
+        return y
+
+    def __del__(self):
+        if self.h:
+            lib().orc_TVConv_destroy(C.byref(self.h))
+
+
 def binaural_mac(inTF, hrtf, nSrc, scale):
     """inTF [nBands][nSrcStride][T] c64, hrtf [nSrc][nBands][2] c64 -> [nBands][2][T]."""
     inTF = np.ascontiguousarray(inTF, np.complex64)

@@ -131,6 +131,13 @@ void orc_ambi_enc_setEnablePostScaling(void* h, int v);
 void orc_matrixConv_create(void** ph, int hopSize, const float* H, int length_h, int nCHin, int nCHout, int usePartFLAG);
 void orc_matrixConv_destroy(void** ph);
 void orc_matrixConv_apply(void* h, const float* in, float* out);
+/* ---- multi-channel and time-varying convolvers (saf_utility_matrixConv.c:237-620) ---- */
+void orc_multiConv_create(void** ph, int hopSize, const float* H /* nCH x length_h */, int length_h, int nCH, int usePartFLAG);
+void orc_multiConv_destroy(void** ph);
+void orc_multiConv_apply(void* h, const float* in /* nCH x hop */, float* out /* nCH x hop */);
+void orc_TVConv_create(void** ph, int hopSize, const float* H /* nIRs x nCHout x length_h, flat */, int length_h, int nIRs, int nCHout, int initIdx);
+void orc_TVConv_destroy(void** ph);
+void orc_TVConv_apply(void* h, const float* in /* hop */, float* out /* nCHout x hop */, int irIdx);
 
 /* ---- binauraliser block path (binauraliser.c:191-285) with caller-supplied per-source HRTF band coefficients ---- */
 void orc_binaural_mac(const orc_cpx* inTF /* [nBands][nSrcStride][T] */, const orc_cpx* hrtf /* [nSrc][nBands][2] */,

@@ -149,6 +149,14 @@ def load():
     sig("saf_matrixConv_apply", None, vp, fp, fp)
     sig("saf_hip_matrixConv_setMaxBlocksPerCall", None, ci)
     sig("saf_hip_matrixConv_apply_dev", None, vp, vp, cll, cll, vp, cll, cll, ci)
+    sig("saf_multiConv_create", None, C.POINTER(vp), ci, fp, ci, ci, ci)
+    sig("saf_multiConv_destroy", None, C.POINTER(vp))
+    sig("saf_multiConv_apply", None, vp, fp, fp)
+    sig("saf_hip_multiConv_apply_dev", None, vp, vp, cll, cll, vp, cll, cll, ci)
+    sig("saf_TVConv_create", None, C.POINTER(vp), ci, C.POINTER(fp), ci, ci, ci, ci)
+    sig("saf_TVConv_destroy", None, C.POINTER(vp))
+    sig("saf_TVConv_apply", None, vp, fp, fp, ci)
+    sig("saf_hip_TVConv_apply_dev", None, vp, vp, cll, vp, cll, cll, C.POINTER(ci), ci)
     # HRIR processing + binauraliser
     sig("estimateITDs", None, fp, ci, ci, ci, fp)
     sig("HRIRs2HRTFs_afSTFT", None, fp, ci, ci, ci, ci, ci, vp)

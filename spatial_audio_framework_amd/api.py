@@ -343,6 +343,64 @@ class MatrixConv:
             self.L.saf_matrixConv_destroy(C.byref(self.h))
 
 
+class MultiConv:
+    """saf_multiConv_* (saf_utility_matrixConv.h:109-137); H [nCH][len]: channel c is filtered by H[c]."""
+
+    def __init__(self, hop, H, part=1, maxBlocks=1):
+        H = np.ascontiguousarray(H, np.float32)
+        self.nCH, self.len = H.shape
+        self.hop = hop
+        self.L = load()
+        self.h = vp()
+        self.L.saf_hip_matrixConv_setMaxBlocksPerCall(maxBlocks)
+        self.L.saf_multiConv_create(C.byref(self.h), hop, _f(H), self.len, self.nCH, part)
+        self.L.saf_hip_matrixConv_setMaxBlocksPerCall(1)
+
+    def apply(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((self.nCH, self.hop), np.float32)
+        self.L.saf_multiConv_apply(self.h, _f(x), _f(y))
+        return y
+
+    def apply_dev(self, d_in, in_strides, d_out, out_strides, nBlocks):
+        """strides = (ch, block) in floats."""
+        self.L.saf_hip_multiConv_apply_dev(self.h, vp(d_in), *in_strides, vp(d_out), *out_strides, nBlocks)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.saf_multiConv_destroy(C.byref(self.h))
+
+
+class TVConv:
+    """saf_TVConv_* (saf_utility_matrixConv.h:157-200); H [nIRs][nCHout][len], one input channel."""
+
+    def __init__(self, hop, H, initIdx=0, maxBlocks=1):
+        H = np.ascontiguousarray(H, np.float32)
+        self.nIRs, self.nOut, self.len = H.shape
+        self.hop = hop
+        self.L = load()
+        self.h = vp()
+        rows = (C.POINTER(C.c_float) * self.nIRs)(*[_f(H[i]) for i in range(self.nIRs)])
+        self.L.saf_hip_matrixConv_setMaxBlocksPerCall(maxBlocks)
+        self.L.saf_TVConv_create(C.byref(self.h), hop, rows, self.len, self.nIRs, self.nOut, initIdx)
+        self.L.saf_hip_matrixConv_setMaxBlocksPerCall(1)
+
+    def apply(self, x, irIdx):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((self.nOut, self.hop), np.float32)
+        self.L.saf_TVConv_apply(self.h, _f(x), _f(y), int(irIdx))
+        return y
+
+    def apply_dev(self, d_in, in_block_stride, d_out, out_strides, irIdx, nBlocks):
+        """out_strides = (ch, block) in floats; irIdx: nBlocks host ints."""
+        idx = (C.c_int * nBlocks)(*[int(i) for i in irIdx])
+        self.L.saf_hip_TVConv_apply_dev(self.h, vp(d_in), in_block_stride, vp(d_out), *out_strides, idx, nBlocks)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.saf_TVConv_destroy(C.byref(self.h))
+
+
 # ---------------------------------------------------------------- HRIR processing / binauraliser
 def estimateITDs(hrirs, fs):
     hrirs = np.ascontiguousarray(hrirs, np.float32)

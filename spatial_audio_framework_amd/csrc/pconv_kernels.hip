@@ -94,6 +94,7 @@ struct MacArgs {
     int nIn, nFB, nOut, nBins, nBinsP, kSplit, termsPerSplit;
     int ringLen, ringHead; /* slot of block t of this call = (ringHead + t) % ringLen */
     int T;
+    int nX, diag;          /* channels per ring slot; diag = 1: output o convolves input channel o only (saf_multiConv), nIn = 1 */
 };
 
 __global__ __launch_bounds__(256) void pconv_mac_kernel(MacArgs a)
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void pconv_mac_kernel(MacArgs a)
                 for (int u = 0; u < MAC_TB; u++) {
                     if (t0 + u >= a.T) break;
                     int slot = (a.ringHead + t0 + u - p) % a.ringLen; if (slot < 0) slot += a.ringLen;
-                    const float2 x = a.Xr[((long long)slot * a.nIn + i) * a.nBinsP + bin];
+                    const float2 x = a.Xr[((long long)slot * a.nX + i + o * a.diag) * a.nBinsP + bin];
                     acc[u].x = fmaf(h.x, x.x, acc[u].x); acc[u].x = fmaf(-h.y, x.y, acc[u].x);
                     acc[u].y = fmaf(h.x, x.y, acc[u].y); acc[u].y = fmaf(h.y, x.x, acc[u].y);
                 }
@@ -203,6 +204,68 @@ __global__ __launch_bounds__(256) void pconv_ola_kernel(OlaArgs a)
 }
 
 /* -------------------------------------------------------------------------- */
+/*  time-varying convolver (saf_TVConv_apply, saf_utility_matrixConv.c:554-620) */
+/* -------------------------------------------------------------------------- */
+
+struct TvMacArgs {
+    const float2* Hf;      /* [nIRs][nOut][nFB][nBinsP] */
+    const float2* Xr;      /* [ringLen][nBinsP] (one input channel) */
+    float2* P;             /* [T][nOut*3][nBinsP] */
+    const int* irSel;      /* [T][3]: IR of block t, of t-1, of t-2 */
+    int nFB, nOut, nBins, nBinsP, ringLen, ringHead;
+};
+
+/* grid (ceil(nBins/64), nOut*3, T); 256 threads = 64 bins x 4 partition groups */
+__global__ __launch_bounds__(256) void tvconv_mac_kernel(TvMacArgs a)
+{
+    __shared__ float2 s_red[4][64];
+    const int b = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int bin = blockIdx.x * 64 + b, ov = blockIdx.y, t = blockIdx.z;
+    const int o = ov / 3, v = ov - 3 * o;
+    const int ir = a.irSel[t * 3 + v];
+    float2 acc = make_float2(0.f, 0.f);
+    if (bin < a.nBins) {
+        const float2* H = a.Hf + ((long long)ir * a.nOut + o) * a.nFB * a.nBinsP + bin;
+        for (int p = q; p < a.nFB; p += 4) {
+            int slot = (a.ringHead + t - p) % a.ringLen; if (slot < 0) slot += a.ringLen;
+            const float2 h = H[(long long)p * a.nBinsP], x = a.Xr[(long long)slot * a.nBinsP + bin];
+            acc.x = fmaf(h.x, x.x, acc.x); acc.x = fmaf(-h.y, x.y, acc.x);
+            acc.y = fmaf(h.x, x.y, acc.y); acc.y = fmaf(h.y, x.x, acc.y);
+        }
+    }
+    s_red[q][b] = acc;
+    __syncthreads();
+    if (q == 0 && bin < a.nBins) {
+        float2 r = s_red[0][b];
+#pragma unroll
+        for (int qq = 1; qq < 4; qq++) { r.x += s_red[qq][b].x; r.y += s_red[qq][b].y; }
+        a.P[((long long)t * a.nOut * 3 + ov) * a.nBinsP + bin] = r;
+    }
+}
+
+struct TvMixArgs {
+    const float* zs;       /* [zRing][nOut*3][N] */
+    float* out; long long out_ch, out_blk;
+    int nOut, N, hop, zRing, zHead;
+};
+
+/* grid (ceil(hop/256), nOut, T):  out = (z_last[n] + tail of the previous block's z_cur) * fadeIn
+ *                                     + (z_last2[n] + tail of the previous block's z_last) * fadeOut      (:600-611) */
+__global__ __launch_bounds__(256) void tvconv_mix_kernel(TvMixArgs a)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, t = blockIdx.z;
+    if (n >= a.hop) return;
+    const int sl = (a.zHead + t) % a.zRing;
+    int sp = (a.zHead + t - 1) % a.zRing; if (sp < 0) sp += a.zRing;
+    const float* zc = a.zs + ((long long)sl * a.nOut * 3 + o * 3) * a.N;
+    const float* zp = a.zs + ((long long)sp * a.nOut * 3 + o * 3) * a.N;
+    const float out1 = __fadd_rn(zc[(long long)1 * a.N + n], zp[(long long)0 * a.N + a.hop + n]);
+    const float out2 = __fadd_rn(zc[(long long)2 * a.N + n], zp[(long long)1 * a.N + a.hop + n]);
+    const float fi = (float)n / (float)(a.hop - 1), fo = (float)(a.hop - 1 - n) / (float)(a.hop - 1);
+    a.out[(long long)t * a.out_blk + (long long)o * a.out_ch + n] = __fadd_rn(__fmul_rn(out1, fi), __fmul_rn(out2, fo));
+}
+
+/* -------------------------------------------------------------------------- */
 /*                                launchers                                   */
 /* -------------------------------------------------------------------------- */
 
@@ -246,6 +309,7 @@ void pconv_launch_apply(const PconvApply& p)
         MacArgs a;
         a.Hf = p.Hf; a.Xr = p.Xr; a.P = p.P; a.nIn = p.nIn; a.nFB = p.nFB; a.nOut = p.nOut; a.nBins = M + 1; a.nBinsP = p.nBinsP;
         a.kSplit = p.kSplit; a.termsPerSplit = p.termsPerSplit; a.ringLen = p.xRing; a.ringHead = p.xHead; a.T = p.T;
+        a.diag = p.diag ? 1 : 0; a.nX = p.diag ? p.nOut : p.nIn;
         KernelTimer kt("pconv_mac");
         hipLaunchKernelGGL(pconv_mac_kernel, dim3((M + 1 + 63) / 64, p.nOut, p.kSplit), dim3(256), 0, stream(), a);
         HIP_CHECK(hipGetLastError());
@@ -263,6 +327,33 @@ void pconv_launch_apply(const PconvApply& p)
         a.zs = p.zs; a.out = p.out; a.out_ch = p.out_ch; a.out_blk = p.out_blk; a.nOut = p.nOut; a.N = p.N; a.hop = p.hop; a.nOB = p.nOB;
         a.zRing = p.zRing; a.zHead = p.zHead;
         hipLaunchKernelGGL(pconv_ola_kernel, dim3((p.hop + 255) / 256, p.nOut, p.T), dim3(256), 0, stream(), a);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+void tvconv_launch_apply(const TvApply& p)
+{
+    const int M = p.N / 2, logM = ilog2(M);
+    {
+        TvMacArgs a;
+        a.Hf = p.Hf; a.Xr = p.Xr; a.P = p.P; a.irSel = p.irSel; a.nFB = p.nFB; a.nOut = p.nOut; a.nBins = M + 1; a.nBinsP = p.nBinsP;
+        a.ringLen = p.xRing; a.ringHead = p.xHead;
+        KernelTimer kt("tvconv_mac");
+        hipLaunchKernelGGL(tvconv_mac_kernel, dim3((M + 1 + 63) / 64, p.nOut * 3, p.T), dim3(256), 0, stream(), a);
+        HIP_CHECK(hipGetLastError());
+    }
+    {
+        InvArgs a;
+        a.P = p.P; a.zs = p.zs; a.tw = p.tw; a.nOut = p.nOut * 3; a.kSplit = 1; a.nBinsP = p.nBinsP; a.M = M; a.logM = logM;
+        a.zRing = p.zRing; a.zHead = p.zHead;
+        KernelTimer kt("pconv_ifft");
+        hipLaunchKernelGGL(pconv_irfft_kernel, dim3(p.nOut * 3, p.T), dim3(256), sizeof(float2) * M, stream(), a);
+        HIP_CHECK(hipGetLastError());
+    }
+    {
+        TvMixArgs a;
+        a.zs = p.zs; a.out = p.out; a.out_ch = p.out_ch; a.out_blk = p.out_blk; a.nOut = p.nOut; a.N = p.N; a.hop = p.hop; a.zRing = p.zRing; a.zHead = p.zHead;
+        hipLaunchKernelGGL(tvconv_mix_kernel, dim3((p.hop + 255) / 256, p.nOut, p.T), dim3(256), 0, stream(), a);
         HIP_CHECK(hipGetLastError());
     }
 }

@@ -177,8 +177,15 @@ struct PconvApply {         /* MAC over (partition, input) + one inverse FFT per
     const float2* Hf; const float2* Xr; float2* P; float* zs; float* out; long long out_ch, out_blk;
     const float2* tw;
     int nIn, nOut, nFB, N, hop, nOB, nBinsP, kSplit, termsPerSplit, xRing, xHead, zRing, zHead, T;
+    int diag = 0;           /* 1: saf_multiConv — output o filters input channel o only (nIn = 1 term per partition) */
 };
 void pconv_launch_apply(const PconvApply& p);
+struct TvApply {            /* saf_TVConv_apply for T blocks: three IR selections per block, inverse FFTs, cross-fade */
+    const float2* Hf; const float2* Xr; float2* P; float* zs; float* out; long long out_ch, out_blk;
+    const float2* tw; const int* irSel;
+    int nOut, nFB, N, hop, nBinsP, xRing, xHead, zRing, zHead, T;
+};
+void tvconv_launch_apply(const TvApply& p);
 void pconv_twiddles(int N, DevBuf<float2>& tw);
 
 /* ---- binaural rendering kernels (binaural_kernels.hip) ---- */

@@ -83,3 +83,75 @@ def test_matrixconv_cfg3b_batched_device_entry(saf, orc):
     assert relrms(ya, yo) < TOL and relrms(ya, direct(H, x)) < TOL
     assert relrms(yb, ya) < 1e-6
     saf.set_stream(None)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# saf_multiConv / saf_TVConv (saf_utility_matrixConv.c:237-620).  The reference only smoke-runs them
+# (no known answers): pinned by the oracle restatement and by float64 direct convolution ("parity unpinned" otherwise).
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("part", [1, 0])
+@pytest.mark.parametrize("hop,L,nCH", [(64, 200, 5), (128, 128, 64), (96, 50, 3), (512, 3000, 8)])
+def test_multiconv_vs_oracle_and_direct(saf, orc, part, hop, L, nCH):
+    H = (np.random.default_rng(hop + L).normal(size=(nCH, L)) / 8).astype(np.float32)
+    x = frames(hop + L + 1, nCH, 7 * hop)
+    yg = run(saf.MultiConv(hop, H, part), x, hop)
+    yo = run(orc.MultiConv(hop, H, part), x, hop)
+    ref = np.stack([np.convolve(x[c].astype(np.float64), H[c].astype(np.float64))[:x.shape[1]] for c in range(nCH)])
+    assert relrms(yg, yo) < TOL and relrms(yg, ref) < TOL
+
+
+def test_multiconv_batched_device_entry(saf, orc):
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    hop, L, nCH, nB = 256, 700, 16, 6
+    H = (np.random.default_rng(8).normal(size=(nCH, L)) / 8).astype(np.float32)
+    x = frames(21, nCH, 2 * nB * hop)
+    g, o = saf.MultiConv(hop, H, 1, maxBlocks=nB), orc.MultiConv(hop, H, 1)
+    d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros_like(d_in)
+    for call in range(2):
+        off = call * nB * hop * 4
+        g.apply_dev(d_in.data_ptr() + off, (2 * nB * hop, hop), d_out.data_ptr() + off, (2 * nB * hop, hop), nB)
+    torch.cuda.synchronize()
+    assert relrms(d_out.cpu().numpy(), run(o, x, hop)) < TOL
+    saf.set_stream(None)
+
+
+@pytest.mark.parametrize("hop,L,nIR,nOut", [(64, 150, 3, 2), (128, 1024, 6, 4), (96, 96, 2, 1)])
+def test_tvconv_vs_oracle(saf, orc, hop, L, nIR, nOut):
+    """IR index switching every few blocks, including back-to-back switches; host-pointer entry, one block per call"""
+    rng = np.random.default_rng(hop)
+    H = (rng.normal(size=(nIR, nOut, L)) / 8).astype(np.float32)
+    nB = 14
+    x = frames(5, 1, nB * hop)[0]
+    idx = [0, 0, 1, 1, 1, nIR - 1, 0, 1, 1, 0, 0, 0, nIR - 1, nIR - 1]
+    g, o = saf.TVConv(hop, H, 0), orc.TVConv(hop, H, 0)
+    yg = np.concatenate([g.apply(x[b * hop:(b + 1) * hop], idx[b]) for b in range(nB)], 1)
+    yo = np.concatenate([o.apply(x[b * hop:(b + 1) * hop], idx[b]) for b in range(nB)], 1)
+    assert np.abs(yo).max() > 0.1 and relrms(yg, yo) < TOL
+    # closed form: block b cross-fades from the convolution with IR idx[b-2] to the one with IR idx[b-1]
+    full = np.stack([[np.convolve(x.astype(np.float64), H[i, c].astype(np.float64))[:nB * hop] for c in range(nOut)] for i in range(nIR)])
+    fi = np.arange(hop) / (hop - 1.0)
+    exp = np.zeros_like(yo, dtype=np.float64)
+    for b in range(nB):
+        s = slice(b * hop, (b + 1) * hop)
+        exp[:, s] = full[idx[b - 1] if b >= 1 else 0][:, s] * fi + full[idx[b - 2] if b >= 2 else 0][:, s] * (1.0 - fi)
+    assert relrms(yg, exp) < TOL
+
+
+def test_tvconv_batched_device_entry(saf, orc):
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    hop, L, nIR, nOut, nB = 512, 4096, 10, 4, 8
+    rng = np.random.default_rng(77)
+    H = (rng.normal(size=(nIR, nOut, L)) / 16).astype(np.float32)
+    x = frames(6, 1, 2 * nB * hop)[0]
+    idx = [int(v) for v in rng.integers(0, nIR, 2 * nB)]
+    g, o = saf.TVConv(hop, H, 3, maxBlocks=nB), orc.TVConv(hop, H, 3)
+    d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros(nOut, 2 * nB * hop, device="cuda")
+    for call in range(2):
+        off = call * nB * hop * 4
+        g.apply_dev(d_in.data_ptr() + off, hop, d_out.data_ptr() + off, (2 * nB * hop, hop), idx[call * nB:(call + 1) * nB], nB)
+    torch.cuda.synchronize()
+    yo = np.concatenate([o.apply(x[b * hop:(b + 1) * hop], idx[b]) for b in range(2 * nB)], 1)
+    assert relrms(d_out.cpu().numpy(), yo) < TOL
+    saf.set_stream(None)

@@ -432,3 +432,39 @@ def test_panner_closed_forms(orc):
     G1 = p.gains()[:, 1, :24]
     pv = p.pvalues()
     assert pv[0] == pytest.approx(1.0) and np.allclose((np.maximum(G1, 0) ** pv[:, None]).sum(-1) ** (1 / pv), 1.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("part,hop,L", [(1, 64, 200), (0, 48, 100), (1, 128, 128)])
+def test_multiConv_vs_direct_convolution(orc, part, hop, L):
+    """saf_multiConv has no known-answer test in the reference: check against float64 np.convolve per channel."""
+    rng = np.random.default_rng(2)
+    nCH, nB = 5, 9
+    H = rng.normal(size=(nCH, L)).astype(np.float32)
+    x = rng.normal(size=(nCH, nB * hop)).astype(np.float32)
+    mc = orc.MultiConv(hop, H, part)
+    y = np.concatenate([mc.apply(np.ascontiguousarray(x[:, b * hop:(b + 1) * hop])) for b in range(nB)], 1)
+    ref = np.stack([np.convolve(x[c].astype(np.float64), H[c].astype(np.float64))[:nB * hop] for c in range(nCH)])
+    assert relrms(y, ref) < 2e-6
+
+
+def test_TVConv_static_and_crossfade(orc):
+    """saf_TVConv: with a constant IR index the output is the plain convolution with that IR; after an index change at
+    block b the output cross-fades linearly from the old to the new IR's convolution over block b + 1 (one block lag)."""
+    rng = np.random.default_rng(3)
+    hop, L, nIR, nOut, nB = 64, 150, 3, 2, 10
+    H = rng.normal(size=(nIR, nOut, L)).astype(np.float32)
+    x = rng.normal(size=(nB * hop,)).astype(np.float32)
+    full = np.stack([[np.convolve(x.astype(np.float64), H[i, o].astype(np.float64))[:nB * hop] for o in range(nOut)] for i in range(nIR)])
+    tv = orc.TVConv(hop, H, 1)
+    idx = [1, 1, 1, 2, 2, 2, 0, 1, 1, 1]
+    y = np.concatenate([tv.apply(x[b * hop:(b + 1) * hop], idx[b]) for b in range(nB)], 1)
+    fi = np.arange(hop) / (hop - 1.0); fo = 1.0 - fi
+    exp = np.zeros_like(y, dtype=np.float64)
+    for b in range(nB):
+        a = idx[b - 1] if b >= 1 else 1            # posIdx_last
+        c = idx[b - 2] if b >= 2 else 1            # posIdx_last2
+        s = slice(b * hop, (b + 1) * hop)
+        exp[:, s] = full[a][:, s] * fi + full[c][:, s] * fo
+    # blocks where the IR was constant over the previous block too are exact convolutions; switched blocks carry the
+    # overlap of the IR that was current one block earlier, which the cross-fade model above reproduces as well
+    assert relrms(y, exp) < 2e-6

@@ -198,6 +198,36 @@ def main():
                 "batch": f"{nI} instances x {nF} blocks per call", "kernels_ms": per,
                 "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": (64 + 2) * F * 4, "path_achieved_GBps": round((64 + 2) * F * 4 * nI * nF / t / 1e9, 1), "peak_GBps": HBM},
                 "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s", "cores": 1, "kind": "port"}})
+
+    # ---- saf_multiConv (64 channels x 4096 taps) and saf_TVConv (1 -> 4 channels, 8192 taps, 64 IR sets, index changes every block)
+    nCH, Lh, hop, nB = 64, 4096, 512, 16
+    Hm = (np.random.default_rng(4).normal(size=(nCH, Lh)) / 32).astype(np.float32)
+    gm = api.MultiConv(hop, Hm, 1, maxBlocks=nB)
+    x = torch.rand(nCH, nB * hop, device="cuda") * 2 - 1; y = torch.zeros(nCH, nB * hop, device="cuda")
+    t, per = timed(L, torch, lambda: gm.apply_dev(x.data_ptr(), (nB * hop, hop), y.data_ptr(), (nB * hop, hop), nB), steps, warm, ["pconv_fft", "pconv_mac", "pconv_ifft"])
+    om = O.MultiConv(hop, Hm, 1); xb = frames(8, nCH, hop)
+    tc = cpu_time(lambda: om.apply(xb), 4.0)
+    out.append({"config": "saf_multiConv (SURVEY 8f-3): 64 channels x 4096-tap filters, hop 512, partitioned", "value": round(nB / t, 1), "unit": "blocks/s",
+                "batch": f"1 handle x {nB} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "alg_bytes_per_call": 2 * nCH * hop * 4 * nB + nCH * 8 * 257 * 8 * 2, "peak_GBps": HBM},
+                "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "blocks/s", "cores": 1, "kind": "port"}})
+    nIR, nO, Lh, hop, nB = 64, 4, 8192, 512, 16
+    Ht = (np.random.default_rng(5).normal(size=(nIR, nO, Lh)) / 64).astype(np.float32)
+    gt = api.TVConv(hop, Ht, 0, maxBlocks=nB)
+    x = torch.rand(nB * hop, device="cuda") * 2 - 1; y = torch.zeros(nO, nB * hop, device="cuda")
+    cnt = [0]
+    def step_tv():
+        idx = [(cnt[0] * nB + b) * 7 % nIR for b in range(nB)]; cnt[0] += 1
+        gt.apply_dev(x.data_ptr(), hop, y.data_ptr(), (nB * hop, hop), idx, nB)
+    t, per = timed(L, torch, step_tv, steps, warm, ["pconv_fft", "tvconv_mac", "pconv_ifft"])
+    ot = O.TVConv(hop, Ht, 0); xb = frames(9, 1, hop)[0]; k = [0]
+    def cpu_tv():
+        k[0] += 1; ot.apply(xb, k[0] * 7 % nIR)
+    tc = cpu_time(cpu_tv, 4.0)
+    out.append({"config": "saf_TVConv (SURVEY 8f-3): 1 -> 4 channels, 8192-tap filters, 64 IR sets, IR index changes every block, hop 512", "value": round(nB / t, 1), "unit": "blocks/s",
+                "batch": f"1 handle x {nB} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "note": "3 x 4 spectral products of 16 partitions x 257 bins per block: launch/latency-bound at this size"},
+                "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "blocks/s", "cores": 1, "kind": "port"}})
     for o in out:
         print(json.dumps(o), flush=True)
 
