@@ -450,6 +450,13 @@ SAF_API void saf_hip_powermap_analysis_dev(void* const hPm, const float* d_in, l
 /** Read-back for parity checks: Cx as [133][nSH][nSH]; the smoothed map on the 812-point scanning grid (returns its length). */
 SAF_API void saf_hip_powermap_getCx(void* const hPm, float_complex* Cx);
 SAF_API int  saf_hip_powermap_getRawPmap(void* const hPm, float* pmap);
+/* Activity-map generators on one nSH x nSH covariance matrix (saf_sh.h / saf_sh.c:1544-1858); host pointers.
+ * Y_grid: nSH x nGrid_dirs, passed as complex like in the reference but real-valued (it is built from real SH). */
+SAF_API void generatePWDmap(int order, float_complex* Cx, float_complex* Y_grid, int nGrid_dirs, float* pmap);                                                  /* saf_sh.c:1544 */
+SAF_API void generateMVDRmap(int order, float_complex* Cx, float_complex* Y_grid, int nGrid_dirs, float regPar, float* pmap, float_complex* w_MVDR_out);       /* saf_sh.c:1586 */
+SAF_API void generateCroPaCLCMVmap(int order, float_complex* Cx, float_complex* Y_grid, int nGrid_dirs, float regPar, float lambda, float* pmap);              /* saf_sh.c:1650 */
+SAF_API void generateMUSICmap(int order, float_complex* Cx, float_complex* Y_grid, int nSources, int nGrid_dirs, int logScaleFlag, float* pmap);               /* saf_sh.c:1754 */
+SAF_API void generateMinNormMap(int order, float_complex* Cx, float_complex* Y_grid, int nSources, int nGrid_dirs, int logScaleFlag, float* pmap);             /* saf_sh.c:1801 */
 
 /* ========================================================================== */
 /*      panner (examples/include/panner.h:83-325) + getPvalues                 */

@@ -475,6 +475,46 @@ class Binauraliser:
             lib().orc_binauraliser_destroy(C.byref(self.h))
 
 
+def _cx(a):
+    return np.ascontiguousarray(a, np.complex64)
+
+
+def generateMVDRmap(order, Cx, Y_grid, regPar=8.0, weights=False):
+    Cx = _cx(Cx); Y = np.ascontiguousarray(Y_grid, np.float32); G = Y.shape[1]
+    pm = np.zeros(G, np.float32); w = np.zeros(((order + 1) ** 2, G), np.complex64)
+    lib().orc_generateMVDRmap(order, Cx.ctypes.data_as(vp), fptr(Y), G, C.c_float(regPar), fptr(pm), w.ctypes.data_as(vp))
+    return (pm, w) if weights else pm
+
+
+def generateCroPaCLCMVmap(order, Cx, Y_grid, regPar=8.0, lam=0.0):
+    Cx = _cx(Cx); Y = np.ascontiguousarray(Y_grid, np.float32); G = Y.shape[1]
+    pm = np.zeros(G, np.float32)
+    lib().orc_generateCroPaCLCMVmap(order, Cx.ctypes.data_as(vp), fptr(Y), G, C.c_float(regPar), C.c_float(lam), fptr(pm))
+    return pm
+
+
+def generateMUSICmap(order, Cx, Y_grid, nSources, logScale=0):
+    Cx = _cx(Cx); Y = np.ascontiguousarray(Y_grid, np.float32); G = Y.shape[1]
+    pm = np.zeros(G, np.float32)
+    lib().orc_generateMUSICmap(order, Cx.ctypes.data_as(vp), fptr(Y), nSources, G, logScale, fptr(pm))
+    return pm
+
+
+def generateMinNormMap(order, Cx, Y_grid, nSources, logScale=0):
+    Cx = _cx(Cx); Y = np.ascontiguousarray(Y_grid, np.float32); G = Y.shape[1]
+    pm = np.zeros(G, np.float32)
+    lib().orc_generateMinNormMap(order, Cx.ctypes.data_as(vp), fptr(Y), nSources, G, logScale, fptr(pm))
+    return pm
+
+
+def herm_eig(A):
+    A = _cx(A); n = A.shape[0]
+    e = np.zeros(n); vr = np.zeros((n, n)); vi = np.zeros((n, n))
+    dp = C.POINTER(C.c_double)
+    lib().orc_herm_eig(n, A.ctypes.data_as(vp), e.ctypes.data_as(dp), vr.ctypes.data_as(dp), vi.ctypes.data_as(dp))
+    return e, vr + 1j * vi
+
+
 # ------------------------------------------------------------------ panner
 class Panner:
     def __init__(self, frameSize=128):

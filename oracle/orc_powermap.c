@@ -1,5 +1,5 @@
 /*
- * orc_powermap.c — CPU restatement of the powermap operator, PWD mode
+ * orc_powermap.c — CPU restatement of the powermap operator (all map modes; the adaptive ones live in orc_pmaps.c)
  * (examples/src/powermap/powermap.c:185-380, powermap_internal.c:46-136; generatePWDmap saf_sh.c:1544-1584).
  * TEST INFRASTRUCTURE ONLY (see saf_oracle.h).  No reference test covers powermap: parity "unpinned"
  * by reference-side data; pinned by closed forms in tests/test_oracle_cpu.py.
@@ -150,18 +150,27 @@ static void analyse_frame(orc_pm* p)
             const orc_cpx* C = &p->Cx[(size_t)band * MAXSH * MAXSH];
             for (int i = 0; i < ns; i++) for (int j = 0; j < ns; j++) { Cg[i * nM + j].re += C[i * nSH + j].re * (1e3f * eq); Cg[i * nM + j].im += C[i * nSH + j].im * (1e3f * eq); }
         }
-        if (p->pmap_mode != 1) { fprintf(stderr, "orc_powermap: only PM_MODE_PWD is restated\n"); abort(); }
-        /* generatePWDmap (saf_sh.c:1544-1584): pmap[d] = Re( y_d^T (C y_d) ) */
+        /* generate powermap (powermap.c:291-341) */
         const float* Yg = p->Y_grid[maxOrder - 1];
-        for (int d = 0; d < G; d++) {
-            float accr = 0.0f, acci = 0.0f;
-            for (int i = 0; i < nM; i++) {
-                float cr = 0.0f, ci = 0.0f;
-                for (int j = 0; j < nM; j++) { cr += Cg[i * nM + j].re * Yg[(size_t)j * G + d]; ci += Cg[i * nM + j].im * Yg[(size_t)j * G + d]; }
-                accr += Yg[(size_t)i * G + d] * cr; acci += Yg[(size_t)i * G + d] * ci;
-            }
-            (void)acci;
-            p->pmap[d] = accr;
+        float trace = 0.0f;
+        for (int i = 0; i < nM; i++) trace += Cg[i * nM + i].re;
+        switch (p->pmap_mode) {
+            default:
+            case 1: {   /* PM_MODE_PWD: generatePWDmap (saf_sh.c:1544-1584): pmap[d] = Re( y_d^T (C y_d) ) */
+                for (int d = 0; d < G; d++) {
+                    float accr = 0.0f;
+                    for (int i = 0; i < nM; i++) {
+                        float cr = 0.0f;
+                        for (int j = 0; j < nM; j++) cr += Cg[i * nM + j].re * Yg[(size_t)j * G + d];
+                        accr += Yg[(size_t)i * G + d] * cr;
+                    }
+                    p->pmap[d] = accr;
+                }
+            } break;
+            case 2: if (trace > 1e-8f) orc_generateMVDRmap(maxOrder, Cg, Yg, G, 8.0f, p->pmap, NULL); else memset(p->pmap, 0, sizeof(float) * G); break;
+            case 3: if (trace > 1e-8f) orc_generateCroPaCLCMVmap(maxOrder, Cg, Yg, G, 8.0f, 0.0f, p->pmap); else memset(p->pmap, 0, sizeof(float) * G); break;
+            case 4: case 5: if (trace > 1e-8f) orc_generateMUSICmap(maxOrder, Cg, Yg, p->nSources, G, p->pmap_mode == 5, p->pmap); else memset(p->pmap, 0, sizeof(float) * G); break;
+            case 6: case 7: if (trace > 1e-8f) orc_generateMinNormMap(maxOrder, Cg, Yg, p->nSources, G, p->pmap_mode == 7, p->pmap); else memset(p->pmap, 0, sizeof(float) * G); break;
         }
         free(Cg);
         for (int i = 0; i < G; i++) p->pmap[i] = (1.0f - p->pmapAvgCoeff) * p->pmap[i] + p->pmapAvgCoeff * p->prev_pmap[i];
@@ -207,6 +216,7 @@ void orc_powermap_setPowermapEQ(void* h, float v, int band) { PP; p->pmapEQ[band
 void orc_powermap_setChOrder(void* h, int v) { PP; if (v != 2 || p->new_masterOrder == 1) p->chOrdering = v; }
 void orc_powermap_setNormType(void* h, int v) { PP; if (v != 3 || p->new_masterOrder == 1) p->norm = v; }
 void orc_powermap_setPowermapAvgCoeff(void* h, float v) { PP; p->pmapAvgCoeff = v < 0.0f ? 0.0f : (v > 0.99999999f ? 0.99999999f : v); }
+void orc_powermap_setNumSources(void* h, int n) { PP; p->nSources = n; }      /* powermap.c:418-422 */
 void orc_powermap_requestPmapUpdate(void* h) { PP; p->recalcPmap = 1; }
 int orc_powermap_getPmap(void* h, const float** grid_dirs, const float** pmap, int* nDirs)
 {

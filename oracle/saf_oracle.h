@@ -188,11 +188,19 @@ void orc_powermap_setPowermapEQ(void* h, float v, int band);
 void orc_powermap_setChOrder(void* h, int v);
 void orc_powermap_setNormType(void* h, int v);
 void orc_powermap_setPowermapAvgCoeff(void* h, float v);
+void orc_powermap_setNumSources(void* h, int n);
 void orc_powermap_requestPmapUpdate(void* h);
 int  orc_powermap_getPmap(void* h, const float** grid_dirs, const float** pmap, int* nDirs);
 const orc_cpx* orc_powermap_getCx(void* h);          /* [133][64*64], row stride nSH of the master order */
 const float* orc_powermap_getRawPmap(void* h);       /* [grid_nDirs] after temporal smoothing */
 int  orc_powermap_getGridNDirs(void* h);
+
+/* ---- adaptive / sub-space activity maps (saf_sh.c:1586-1858); Y_grid is the REAL [nSH][G] matrix (the reference passes it as complex with zero imaginary part) ---- */
+void orc_generateMVDRmap(int order, const orc_cpx* Cx, const float* Y_grid, int G, float regPar, float* pmap, orc_cpx* w_MVDR_out /* [nSH][G] or NULL */);
+void orc_generateCroPaCLCMVmap(int order, const orc_cpx* Cx, const float* Y_grid, int G, float regPar, float lambda, float* pmap);
+void orc_generateMUSICmap(int order, const orc_cpx* Cx, const float* Y_grid, int nSources, int G, int logScaleFlag, float* pmap);
+void orc_generateMinNormMap(int order, const orc_cpx* Cx, const float* Y_grid, int nSources, int G, int logScaleFlag, float* pmap);
+void orc_herm_eig(int n, const orc_cpx* A, double* eig /* descending */, double* Vre, double* Vim /* [n][n], columns = eigenvectors */);
 
 /* ---- panner (examples/src/panner) and getPvalues (saf_vbap.c:475-492) ---- */
 void orc_getPvalues(float DTT, const float* freq, int nFreq, float* pValues);

@@ -222,6 +222,12 @@ def load():
     sig("panner_getProgressBarText", None, vp, C.c_char_p)
     sig("saf_hip_panner_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci)
     sig("saf_hip_panner_getGains", None, vp, fp)
+    # activity-map generators
+    sig("generatePWDmap", None, ci, vp, vp, ci, fp)
+    sig("generateMVDRmap", None, ci, vp, vp, ci, cf, fp, vp)
+    sig("generateCroPaCLCMVmap", None, ci, vp, vp, ci, cf, cf, fp)
+    sig("generateMUSICmap", None, ci, vp, vp, ci, ci, ci, fp)
+    sig("generateMinNormMap", None, ci, vp, vp, ci, ci, ci, fp)
     # powermap
     sig("saf_hip_powermap_setFrameSize", None, ci)
     sig("powermap_create", None, C.POINTER(vp))

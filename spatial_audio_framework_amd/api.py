@@ -523,7 +523,41 @@ def getPvalues(DTT, freq):
     return out
 
 
-# ---------------------------------------------------------------- powermap (PWD)
+# ---------------------------------------------------------------- activity-map generators (saf_sh.c:1544-1858)
+def _cxY(Cx, Y_grid):
+    Cx = np.ascontiguousarray(Cx, np.complex64)
+    Y = np.ascontiguousarray(np.asarray(Y_grid, np.float32).astype(np.complex64))
+    return Cx, Y, Y.shape[1]
+
+
+def generatePWDmap(order, Cx, Y_grid):
+    Cx, Y, G = _cxY(Cx, Y_grid); pm = np.zeros(G, np.float32)
+    load().generatePWDmap(order, Cx.ctypes.data_as(vp), Y.ctypes.data_as(vp), G, _f(pm)); return pm
+
+
+def generateMVDRmap(order, Cx, Y_grid, regPar=8.0, weights=False):
+    Cx, Y, G = _cxY(Cx, Y_grid); pm = np.zeros(G, np.float32)
+    w = np.zeros(((order + 1) ** 2, G), np.complex64)
+    load().generateMVDRmap(order, Cx.ctypes.data_as(vp), Y.ctypes.data_as(vp), G, C.c_float(regPar), _f(pm), w.ctypes.data_as(vp) if weights else None)
+    return (pm, w) if weights else pm
+
+
+def generateCroPaCLCMVmap(order, Cx, Y_grid, regPar=8.0, lam=0.0):
+    Cx, Y, G = _cxY(Cx, Y_grid); pm = np.zeros(G, np.float32)
+    load().generateCroPaCLCMVmap(order, Cx.ctypes.data_as(vp), Y.ctypes.data_as(vp), G, C.c_float(regPar), C.c_float(lam), _f(pm)); return pm
+
+
+def generateMUSICmap(order, Cx, Y_grid, nSources, logScale=0):
+    Cx, Y, G = _cxY(Cx, Y_grid); pm = np.zeros(G, np.float32)
+    load().generateMUSICmap(order, Cx.ctypes.data_as(vp), Y.ctypes.data_as(vp), nSources, G, logScale, _f(pm)); return pm
+
+
+def generateMinNormMap(order, Cx, Y_grid, nSources, logScale=0):
+    Cx, Y, G = _cxY(Cx, Y_grid); pm = np.zeros(G, np.float32)
+    load().generateMinNormMap(order, Cx.ctypes.data_as(vp), Y.ctypes.data_as(vp), nSources, G, logScale, _f(pm)); return pm
+
+
+# ---------------------------------------------------------------- powermap
 class Powermap:
     """examples/include/powermap.h.  `frameSize` plays the role of -DPOWERMAP_FRAME_SIZE."""
 

@@ -48,7 +48,8 @@ struct Powermap {
     AfState st; int stftCh = 0;
     int Hmax = 0;
     DevBuf<float2> X, Cx;
-    DevBuf<float> Ygrid[SAF_MAX_ORDER], Cg, d_pmap, d_prev, d_bandScale, d_chScale, d_in;
+    DevBuf<float> Ygrid[SAF_MAX_ORDER], Cg, d_pmap, d_prev, d_bandScale, d_chScale, d_in, d_adapt;
+    DevBuf<double2> d_chol;
     DevBuf<int> d_bandNSH, d_chMap;
     PinBuf<float> stF, h_in, h_pmap; PinBuf<int> stI;
     int shadowNorm = -1, shadowChOrd = -1, shadowOrder = -1;
@@ -99,9 +100,6 @@ static void analyse_frames_dev(Powermap* p, const float* d_in, long long in_fram
 
     if (p->recalcPmap == 1) {
         p->recalcPmap = 0; p->pmapReady = 0;
-        if (p->pmap_mode != 1 /* PM_MODE_PWD */)
-            SAF_FATAL("powermap: mode %d needs a Hermitian eigen-decomposition / solve per map (saf_sh.c:1586-1858), which this build does not "
-                      "implement; only PM_MODE_PWD is available (powermap_setPowermapMode(h, PM_MODE_PWD)).", p->pmap_mode);
         int maxOrder = 1;
         for (int i = 0; i < SAF_NBANDS; i++) { const int o = p->analysisOrderPerBand[i] < masterOrder ? p->analysisOrderPerBand[i] : masterOrder; if (o > maxOrder) maxOrder = o; }
         HIP_CHECK(hipStreamSynchronize(stream()));
@@ -112,11 +110,28 @@ static void analyse_frames_dev(Powermap* p, const float* d_in, long long in_fram
         }
         HIP_CHECK(hipMemcpyAsync(p->d_bandNSH.p, p->stI.p, sizeof(int) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
         HIP_CHECK(hipMemcpyAsync(p->d_bandScale.p, p->stF.p, sizeof(float) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
-        PwdLaunch w{};
-        w.Cx = p->Cx.p; w.bandScale = p->d_bandScale.p; w.bandNSH = p->d_bandNSH.p; w.Cg = p->Cg.p;
-        w.Ygrid = p->Ygrid[maxOrder - 1].p; w.pmap = p->d_pmap.p; w.prev_pmap = p->d_prev.p;
-        w.nM = ORDER2NSH(maxOrder); w.G = p->grid_nDirs; w.avg = p->pmapAvgCoeff;
-        launch_pwd_map(w);
+        if (p->pmap_mode >= 2 && p->pmap_mode <= 7) {       /* PM_MODE_MVDR .. PM_MODE_MINNORM_LOG (powermap.c:299-341) */
+            if (!p->d_adapt.p) {
+                /* scratch: complex C_grp [64][64] | eigenvectors [64][64] | Un [64] | eig [64] | status, and the float64 factor */
+                p->d_adapt.alloc((size_t)2 * 64 * 64 * 2 + 64 * 2 + 64 + 4);
+                p->d_chol.alloc((size_t)64 * 64);
+            }
+            AdaptMapLaunch m{};
+            m.Cx = p->Cx.p; m.bandScale = p->d_bandScale.p; m.bandNSH = p->d_bandNSH.p;
+            float* sc = p->d_adapt.p;
+            m.Cg = (float2*)sc; m.Veig = (float2*)(sc + 64 * 64 * 2); m.Un = (float2*)(sc + 2 * 64 * 64 * 2); m.eig = sc + 2 * 64 * 64 * 2 + 64 * 2;
+            m.status = (int*)(sc + 2 * 64 * 64 * 2 + 64 * 2 + 64); m.Lchol = p->d_chol.p;
+            m.Ygrid = p->Ygrid[maxOrder - 1].p; m.pmap = p->d_pmap.p; m.prev_pmap = p->d_prev.p;
+            m.nM = ORDER2NSH(maxOrder); m.G = p->grid_nDirs; m.mode = p->pmap_mode; m.nSources = p->nSources; m.avg = p->pmapAvgCoeff;
+            m.regPar = 8.0f; m.lambda = 0.0f;
+            launch_adaptive_map(m);
+        } else {                                             /* PM_MODE_PWD and unknown ids (the switch's default, powermap.c:295-298) */
+            PwdLaunch w{};
+            w.Cx = p->Cx.p; w.bandScale = p->d_bandScale.p; w.bandNSH = p->d_bandNSH.p; w.Cg = p->Cg.p;
+            w.Ygrid = p->Ygrid[maxOrder - 1].p; w.pmap = p->d_pmap.p; w.prev_pmap = p->d_prev.p;
+            w.nM = ORDER2NSH(maxOrder); w.G = p->grid_nDirs; w.avg = p->pmapAvgCoeff;
+            launch_pwd_map(w);
+        }
         const int G = p->grid_nDirs;
         HIP_CHECK(hipMemcpyAsync(p->h_pmap.p, p->d_pmap.p, sizeof(float) * G, hipMemcpyDeviceToHost, stream()));
         HIP_CHECK(hipStreamSynchronize(stream()));
@@ -367,5 +382,56 @@ void saf_hip_powermap_getCx(void* const hPm, float_complex* Cx)
     for (int b = 0; b < SAF_NBANDS; b++) for (int i = 0; i < nSH; i++) for (int j = 0; j < nSH; j++) o[((size_t)b * nSH + i) * nSH + j] = h[(size_t)b * 4096 + i * 64 + j];
 }
 int saf_hip_powermap_getRawPmap(void* const hPm, float* pmap) { PPM; memcpy(pmap, p->pmap.data(), sizeof(float) * p->pmap.size()); return (int)p->pmap.size(); }
+
+/* ---- stand-alone map generators (saf_sh.h / saf_sh.c:1544-1858): one nSH x nSH covariance, host pointers.
+ *      Y_grid is passed as complex like in the reference but must be real-valued (all its callers build it from real SH). ---- */
+static void run_generate_map(int mode, int order, const float_complex* Cx, const float_complex* Y_grid, int G, float regPar, float lambda,
+                             int nSources, float* pmap, float_complex* w_out)
+{
+    ensure_device();
+    const int nSH = ORDER2NSH(order);
+    if (order < 1 || order > SAF_MAX_ORDER || G < 1) SAF_FATAL("generate*map: order 1..7 and at least one grid direction");
+    std::vector<float2> C((size_t)64 * 64, make_float2(0.f, 0.f));
+    const float2* cx = reinterpret_cast<const float2*>(Cx);
+    for (int i = 0; i < nSH; i++) for (int j = 0; j < nSH; j++) C[(size_t)i * 64 + j] = cx[(size_t)i * nSH + j];
+    std::vector<float> Y((size_t)nSH * G);
+    const float2* yg = reinterpret_cast<const float2*>(Y_grid);
+    for (size_t i = 0; i < Y.size(); i++) { if (yg[i].y != 0.0f) SAF_FATAL("generate*map: Y_grid must be real-valued (zero imaginary parts)"); Y[i] = yg[i].x; }
+    DevBuf<float2> dC, dSc, dW; DevBuf<float> dY, dP, dPrev, dScale, dEig; DevBuf<int> dN, dSt; DevBuf<double2> dL;
+    dC.alloc(C.size(), false); dSc.alloc((size_t)2 * 64 * 64 + 64); dY.alloc(Y.size(), false); dP.alloc(G); dPrev.alloc(G); dScale.alloc(1, false); dN.alloc(1, false);
+    dSt.alloc(1); dEig.alloc(64); dL.alloc((size_t)64 * 64);
+    if (w_out) dW.alloc((size_t)nSH * G);
+    const float one = 1.0f;
+    HIP_CHECK(hipMemcpyAsync(dC.p, C.data(), sizeof(float2) * C.size(), hipMemcpyHostToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(dY.p, Y.data(), sizeof(float) * Y.size(), hipMemcpyHostToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(dScale.p, &one, sizeof(float), hipMemcpyHostToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(dN.p, &nSH, sizeof(int), hipMemcpyHostToDevice, stream()));
+    if (mode == 1) {
+        DevBuf<float> dCg; dCg.alloc((size_t)64 * 64);
+        PwdLaunch w{};
+        w.Cx = dC.p; w.bandScale = dScale.p; w.bandNSH = dN.p; w.Cg = dCg.p; w.Ygrid = dY.p; w.pmap = dP.p; w.prev_pmap = dPrev.p;
+        w.nM = nSH; w.G = G; w.avg = 0.0f; w.nBands = 1;
+        launch_pwd_map(w);
+        HIP_CHECK(hipStreamSynchronize(stream()));
+    } else {
+        AdaptMapLaunch m{};
+        m.Cx = dC.p; m.bandScale = dScale.p; m.bandNSH = dN.p; m.Cg = dSc.p; m.Veig = dSc.p + 64 * 64; m.Un = dSc.p + 2 * 64 * 64; m.eig = dEig.p; m.status = dSt.p; m.Lchol = dL.p;
+        m.Ygrid = dY.p; m.pmap = dP.p; m.prev_pmap = dPrev.p; m.nM = nSH; m.G = G; m.mode = mode; m.nSources = nSources; m.avg = 0.0f; m.regPar = regPar; m.lambda = lambda;
+        m.nBands = 1; m.Wout = w_out ? dW.p : nullptr;
+        launch_adaptive_map(m);
+    }
+    HIP_CHECK(hipMemcpyAsync(pmap, dP.p, sizeof(float) * G, hipMemcpyDeviceToHost, stream()));
+    if (w_out) HIP_CHECK(hipMemcpyAsync((void*)w_out, dW.p, sizeof(float2) * (size_t)nSH * G, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipStreamSynchronize(stream()));
+}
+void generatePWDmap(int order, float_complex* Cx, float_complex* Y_grid, int nGrid_dirs, float* pmap) { run_generate_map(1, order, Cx, Y_grid, nGrid_dirs, 0.f, 0.f, 0, pmap, nullptr); }
+void generateMVDRmap(int order, float_complex* Cx, float_complex* Y_grid, int nGrid_dirs, float regPar, float* pmap, float_complex* w_MVDR_out)
+{ run_generate_map(2, order, Cx, Y_grid, nGrid_dirs, regPar, 0.f, 0, pmap, w_MVDR_out); }
+void generateCroPaCLCMVmap(int order, float_complex* Cx, float_complex* Y_grid, int nGrid_dirs, float regPar, float lambda, float* pmap)
+{ run_generate_map(3, order, Cx, Y_grid, nGrid_dirs, regPar, lambda, 0, pmap, nullptr); }
+void generateMUSICmap(int order, float_complex* Cx, float_complex* Y_grid, int nSources, int nGrid_dirs, int logScaleFlag, float* pmap)
+{ run_generate_map(logScaleFlag ? 5 : 4, order, Cx, Y_grid, nGrid_dirs, 0.f, 0.f, nSources, pmap, nullptr); }
+void generateMinNormMap(int order, float_complex* Cx, float_complex* Y_grid, int nSources, int nGrid_dirs, int logScaleFlag, float* pmap)
+{ run_generate_map(logScaleFlag ? 7 : 6, order, Cx, Y_grid, nGrid_dirs, 0.f, 0.f, nSources, pmap, nullptr); }
 
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void cgrp_kernel(PwdArgs a)
     const int e = blockIdx.x * 256 + threadIdx.x;          /* all 64 x 64 entries: outside the nM x nM block the sum is empty */
     const int i = e >> 6, j = e & 63;
     float acc = 0.0f;
-    for (int band = 0; band < SAF_NBANDS; band++) {
+    for (int band = 0; band < l.nBands; band++) {
         const int ns = l.bandNSH[band];
         if (i < ns && j < ns) acc += l.Cx[(long long)band * 64 * 64 + i * 64 + j].x * l.bandScale[band];   /* crmulf then ccaddf (powermap.c:288) */
     }

@@ -243,7 +243,23 @@ struct PwdLaunch {              /* grouped covariance + PWD map + temporal smoot
     const float* Ygrid;         /* [nM][G] scaled 1/nM */
     float* pmap; float* prev_pmap;
     int nM, G; float avg;
+    int nBands = SAF_NBANDS;
 };
 void launch_pwd_map(const PwdLaunch& l);
+struct AdaptMapLaunch {         /* MVDR / CroPaC-LCMV / MUSIC / MinNorm maps (powermap.c:294-341, saf_sh.c:1586-1858) */
+    const float2* Cx; const float* bandScale; const int* bandNSH;
+    float2* Cg;                 /* scratch [64][64] grouped complex covariance */
+    double2* Lchol;             /* scratch [64][64] Cholesky factor */
+    float2* Veig;               /* scratch [64][64] eigenvectors in columns, descending eigenvalues */
+    float* eig;                 /* scratch [64] */
+    float2* Un;                 /* scratch [64] min-norm vector */
+    int* status;                /* scratch [1] */
+    const float* Ygrid;         /* [nM][G] scaled 1/nM */
+    float* pmap; float* prev_pmap;
+    int nM, G, mode, nSources; float avg, regPar, lambda;
+    int nBands = SAF_NBANDS;    /* covariance matrices to group (1 for the stand-alone generate*map entry points) */
+    float2* Wout = nullptr;     /* optional [nM][G] MVDR weights (generateMVDRmap's w_MVDR_out) */
+};
+void launch_adaptive_map(const AdaptMapLaunch& l);
 
 }  // namespace saf

@@ -86,3 +86,116 @@ def test_powermap_device_entry_equals_frame_by_frame(saf, orc):
     torch.cuda.synchronize()
     assert relrms(g.Cx(nSH), o.Cx(nSH)) < TOL
     saf.set_stream(None)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# MVDR / CroPaC-LCMV / MUSIC / MinNorm maps (saf_sh.c:1586-1858, powermap.c:294-341).
+# The reference holds no test for these generators ("parity unpinned"); the oracle restates them with float64
+# factorisations and is itself checked against closed forms in tests/test_oracle_cpu.py.  The sub-space maps are
+# reciprocals of a quantity that vanishes at the source directions, so they are compared through that quantity
+# (1 / map) with an absolute tolerance tied to its scale, plus the peak positions; MVDR / CroPaC maps by relative RMS.
+# ----------------------------------------------------------------------------------------------------------------
+def ang(a, b):
+    """great-circle angle in degrees between direction a [azi, elev] and the rows of b"""
+    a, b = np.radians(np.atleast_2d(a)), np.radians(np.atleast_2d(b))
+    c = np.sin(a[:, 1]) * np.sin(b[:, 1]) + np.cos(a[:, 1]) * np.cos(b[:, 1]) * np.cos(a[:, 0] - b[:, 0])
+    return np.degrees(np.arccos(np.clip(c, -1, 1)))
+
+
+def scene(orc, order, nSrc, seed, snr=0.01, cplx=True):
+    rng = np.random.default_rng(seed)
+    nSH = (order + 1) ** 2
+    grid = orc.table("geosphere_ico_9_0_dirs_deg")
+    Yg = (orc.getRSH(order, grid) / nSH).astype(np.float32)
+    src = rng.choice(len(grid), nSrc, replace=False)
+    Ys = orc.getRSH(order, grid[src])
+    L = 4000
+    s = (rng.normal(size=(nSrc, L)) + 1j * rng.normal(size=(nSrc, L))) * (1.0 + 0.5 * np.arange(nSrc))[:, None]
+    x = Ys @ s + snr * (rng.normal(size=(nSH, L)) + 1j * rng.normal(size=(nSH, L)))
+    if cplx:
+        x = x * np.exp(1j * rng.uniform(0, 2 * np.pi, (nSH, 1)) * 0.05)        # slightly complex mixing: Hermitian, not real, covariance
+    Cx = (x @ x.conj().T / L).astype(np.complex64)
+    return Cx, Yg, src
+
+
+@pytest.mark.parametrize("order,nSrc", [(7, 3), (3, 2), (2, 1), (5, 4)])
+def test_generate_maps_vs_oracle(saf, orc, order, nSrc):
+    Cx, Yg, src = scene(orc, order, nSrc, 10 * order + nSrc)
+    grid = orc.table("geosphere_ico_9_0_dirs_deg")
+    # PWD and MVDR (+ weights), CroPaC
+    assert relrms(saf.generatePWDmap(order, Cx, Yg), (np.einsum("id,ij,jd->d", Yg, Cx, Yg)).real) < 1e-5
+    mg, wg = saf.generateMVDRmap(order, Cx, Yg, 8.0, weights=True)
+    mo, wo = orc.generateMVDRmap(order, Cx, Yg, 8.0, weights=True)
+    assert relrms(mg, mo) < 1e-5 and relrms(wg, wo) < 1e-5
+    assert np.abs((wg * Yg).sum(0) - 1).max() < 1e-5                          # distortionless response
+    assert relrms(saf.generateCroPaCLCMVmap(order, Cx, Yg, 8.0, 0.0), orc.generateCroPaCLCMVmap(order, Cx, Yg, 8.0, 0.0)) < 5e-5
+    # sub-space maps
+    for gen_g, gen_o, eps in ((saf.generateMUSICmap, orc.generateMUSICmap, 2.23e-10), (saf.generateMinNormMap, orc.generateMinNormMap, 2.23e-9)):
+        pg, po = gen_g(order, Cx, Yg, nSrc), gen_o(order, Cx, Yg, nSrc)
+        assert np.abs(1.0 / pg - 1.0 / po).max() < 5e-6 * (1.0 / po).max() + 10 * eps       # float32 sums of the projections
+        assert pg.argmax() == po.argmax() and ang(grid[po.argmax()], grid[src]).min() < 8.0     # peak at (or next to) a source
+        assert all(pg[k] > 20 * np.median(pg) for k in src)                    # every source stands out of the floor
+        lg, lo = gen_g(order, Cx, Yg, nSrc, 1), gen_o(order, Cx, Yg, nSrc, 1)
+        far = po < 0.01 * po.max()                                             # away from the poles of the pseudo-spectrum
+        assert np.abs(lg - lo)[far].max() < 1e-3 and relrms(pg[far], po[far]) < 1e-4
+
+
+def test_generate_maps_degenerate_inputs(saf, orc):
+    """zero covariance -> zero maps (powermap.c guards with the trace; the stand-alone generators divide by zero in the
+    reference, here they return zeros); more sources than nSH/2 are clamped (saf_sh.c:1768, :1817)."""
+    order = 2
+    Cx, Yg, src = scene(orc, order, 2, 1)
+    assert np.all(saf.generateMVDRmap(order, np.zeros_like(Cx), Yg) == 0)
+    assert relrms(saf.generateMUSICmap(order, Cx, Yg, 40), saf.generateMUSICmap(order, Cx, Yg, 4)) == 0.0
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4, 5, 6, 7])
+def test_powermap_adaptive_modes_vs_oracle(saf, orc, mode):
+    """powermap_analysis end to end in every map mode: order 5 with lower orders in the upper bands, two sources + noise,
+    covariance and map averaging, three map requests."""
+    order, F, nSH = 5, 1024, 36
+    g, o = mk(saf.Powermap, F, order, norm=1), mk(orc.Powermap, F, order, norm=1)
+    for pm in (g, o):
+        pm.setPowermapMode(mode); pm.setNumSources(2)
+        for b in range(80, 133):
+            pm.setAnaOrder(3, b)
+    srcs = orc.getRSH(order, np.array([[50.0, 20.0], [-100.0, -30.0]], np.float32))
+    s = frames(18, 2, 6 * F) * np.array([[1.0], [0.7]], np.float32)
+    x = (srcs @ s + 0.02 * frames(19, nSH, 6 * F)).astype(np.float32)
+    grid = orc.table("geosphere_ico_9_0_dirs_deg")
+    for f in range(6):
+        if f in (2, 4, 5):
+            g.requestPmapUpdate(); o.requestPmapUpdate()
+        blk = x[:, f * F:(f + 1) * F]
+        g.analysis(blk); o.analysis(blk)
+        if f in (2, 4, 5):
+            rg, ro = g.rawPmap(), o.rawPmap()
+            assert np.isfinite(rg).all()
+            if mode in (2, 3):
+                assert relrms(rg, ro) < 1e-4, f
+            elif mode == 4:
+                far = ro < 0.01 * ro.max()
+                assert relrms(rg[far], ro[far]) < 1e-3 and rg.argmax() == ro.argmax(), f
+            elif mode == 5:
+                assert np.abs(rg - ro).max() < 5e-3 * max(1.0, np.abs(ro).max()), f
+            else:
+                # MinNorm divides by sum_j Vn1_j^2 WITHOUT conjugation (saf_sh.c:1832): that scalar is not invariant to the
+                # basis chosen inside clusters of near-equal noise eigenvalues, so two correct eigen-solvers agree on the map
+                # only up to ONE global factor (an offset in the log map); the displayed, normalised map is unaffected.
+                # The smoothing mixes maps with different factors, so only the first request is compared this way.
+                if f == 2:
+                    if mode == 6:
+                        ig, io = 1.0 / rg.astype(np.float64), 1.0 / ro.astype(np.float64)       # |Un^H y|^2 up to the factor
+                        k = float(ig @ io / (io @ io))
+                        # measured: the ORACLE's own map moves by 8e-4 of its maximum (beyond the factor) when its input is
+                        # perturbed by 2e-7 relative, MUSIC by 4e-7; on identical input GPU and oracle agree to 1e-6
+                        # (test_generate_maps_vs_oracle), so this bound reflects the formula's conditioning, not the solver
+                        assert 0.5 < k < 2.0 and np.abs(ig - k * io).max() < 5e-3 * io.max(), f
+                    else:
+                        assert np.abs((rg - ro) - np.mean(rg - ro)).max() < 5e-3 * max(1.0, np.abs(ro).max()), f
+                assert ang(grid[rg.argmax()], grid[ro.argmax()]).min() < 8.0
+            az, el = grid[rg.argmax()]
+            if mode < 6:      # (mixed per-band orders make every source rank 2 in the grouped covariance: MinNorm with nSources = 2 is biased)
+                assert min(np.hypot(az - 50, el - 20), np.hypot(az + 100, el + 30)) < 8.0
+            if mode < 6:
+                assert g.getPmap().argmax() == o.getPmap().argmax()

@@ -468,3 +468,33 @@ def test_TVConv_static_and_crossfade(orc):
     # blocks where the IR was constant over the previous block too are exact convolutions; switched blocks carry the
     # overlap of the IR that was current one block earlier, which the cross-fade model above reproduces as well
     assert relrms(y, exp) < 2e-6
+
+
+def test_adaptive_map_generators_closed_forms(orc):
+    """generateMVDRmap / CroPaCLCMV / MUSIC / MinNorm have no reference test.  Closed forms: the Hermitian
+    eigen-solver reproduces A V = V diag(e) with orthonormal V, descending e and cgeev-style phases; MVDR weights are
+    distortionless (w^T y = 1); all four maps peak at the true source directions of a two-source scene (the design of
+    the reference's test__sphMUSIC); a zero covariance gives a zero MVDR map."""
+    rng = np.random.default_rng(0)
+    n = 16
+    X = rng.normal(size=(n, 40)) + 1j * rng.normal(size=(n, 40))
+    A = (X @ X.conj().T / 40).astype(np.complex64)
+    e, V = orc.herm_eig(A)
+    assert np.abs(A.astype(np.complex128) @ V - V * e).max() < 1e-12 and np.abs(V.conj().T @ V - np.eye(n)).max() < 1e-12
+    assert np.all(np.diff(e) <= 0) and np.allclose(e, np.linalg.eigvalsh(A.astype(np.complex128))[::-1], rtol=1e-12)
+    k = np.abs(V).argmax(0)
+    assert np.abs(V[k, np.arange(n)].imag).max() < 1e-15 and V[k, np.arange(n)].real.min() > 0
+    order, nSH = 3, 16
+    grid = orc.table("Tdesign_degree_21_dirs_deg")
+    Yg = (orc.getRSH(order, grid) / nSH).astype(np.float32)
+    src = [139, 204]                                                          # the directions of test__sphMUSIC (test__sh_module.c:472-473)
+    s = rng.normal(size=(2, 5000)) + 1j * rng.normal(size=(2, 5000))
+    x = orc.getRSH(order, grid[src]) @ s + 0.01 * (rng.normal(size=(nSH, 5000)) + 1j * rng.normal(size=(nSH, 5000)))
+    Cx = (x @ x.conj().T / 5000).astype(np.complex64)
+    for pm in (orc.generateMUSICmap(order, Cx, Yg, 2), orc.generateMinNormMap(order, Cx, Yg, 2), orc.generateMVDRmap(order, Cx, Yg),
+               orc.generateCroPaCLCMVmap(order, Cx, Yg)):
+        assert set(np.argsort(pm)[::-1][:2]) == set(src)
+    assert np.allclose(np.exp(orc.generateMUSICmap(order, Cx, Yg, 2, 1)), orc.generateMUSICmap(order, Cx, Yg, 2), rtol=1e-4)
+    pm, w = orc.generateMVDRmap(order, Cx, Yg, weights=True)
+    assert np.abs((w * Yg).sum(0) - 1).max() < 1e-5
+    assert np.all(orc.generateMVDRmap(order, np.zeros_like(Cx), Yg) == 0)

@@ -228,6 +228,22 @@ def main():
                 "batch": f"1 handle x {nB} blocks per call", "kernels_ms": per,
                 "roofline": {"bound": "hbm", "note": "3 x 4 spectral products of 16 partitions x 257 bins per block: launch/latency-bound at this size"},
                 "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "blocks/s", "cores": 1, "kind": "port"}})
+
+    # ---- powermap in MUSIC and MVDR modes (order 7, F = 1024, one map per call)
+    for mode, name in ((4, "MUSIC"), (2, "MVDR")):
+        gp2 = mkpm(api.Powermap); gp2.setPowermapMode(mode); gp2.setNumSources(2)
+        xs = torch.rand(64, 16 * 1024, device="cuda") * 2 - 1
+        def step_pm2():
+            gp2.requestPmapUpdate(); gp2.analysis_dev(xs.data_ptr(), (1024, 16 * 1024), 64, 16)
+        t, per = timed(L, torch, step_pm2, steps, warm, ["afstft_analysis", "cov_update", "adaptive_map"])
+        op2 = mkpm(O.Powermap); op2.setPowermapMode(mode); op2.setNumSources(2); xb = frames(4, 64, 1024)
+        def cpu_pm2():
+            op2.requestPmapUpdate(); op2.analysis(xb)
+        tc = cpu_time(cpu_pm2, 6.0)
+        out.append({"config": f"powermap {name} mode (SURVEY 8f-4): 64-channel (order 7) input, F = 1024, 812-direction map, one map per call", "value": round(16 / t, 1), "unit": "frames/s",
+                    "batch": "1 handle x 16 frames per call", "kernels_ms": per,
+                    "roofline": {"bound": "latency", "note": "one 64 x 64 factorisation per map in a single workgroup (float64 in LDS)"},
+                    "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s (map every frame; float64 Jacobi / Cholesky port)", "cores": 1, "kind": "port"}})
     for o in out:
         print(json.dumps(o), flush=True)
 
