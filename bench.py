@@ -123,6 +123,10 @@ def main():
     def step(i):
         batch.process_ptr(xs[i & 1].data_ptr(), st, y.data_ptr(), st, nF)
 
+    # The headline number is measured on the general path (afSTFT analysis -> per-band MFMA GEMM -> synthesis), which
+    # is valid for any per-band decoder / order assignment.  This workload's decoder happens to be the same in every
+    # band; the library's shortcut for that case is timed separately below and reported as `band_independent_path`.
+    L.saf_hip_ambi_dec_setTimeDomainPath(0)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -138,6 +142,35 @@ def main():
     elapsed = time.perf_counter() - t0
     L.saf_hip_profile_enable(0)
     elapsed = P.max_over_ranks(elapsed, device=dev)
+    general_kernels = {}
+    for k in ALG_BYTES_PER_FRAME:
+        tot = C.c_double()
+        n = L.saf_hip_profile_read(k.encode(), C.byref(tot))
+        if n:
+            general_kernels[k] = (tot.value / n, n)
+
+    # ---- the same steps through the band-independent shortcut (time-domain GEMM + transform-free filterbank round trip)
+    L.saf_hip_ambi_dec_setTimeDomainPath(1)
+    for i in range(max(2, args.warmup)):
+        step(i)
+    torch.cuda.synchronize()
+    L.saf_hip_profile_reset()
+    L.saf_hip_profile_enable(0 if args.no_profile else 1)
+    P.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    P.barrier()
+    elapsed_td = P.max_over_ranks(time.perf_counter() - t1, device=dev)
+    L.saf_hip_profile_enable(0)
+    td_kernels = {}
+    for k in ("band_gemm", "afstft_roundtrip"):
+        tot = C.c_double()
+        n = L.saf_hip_profile_read(k.encode(), C.byref(tot))
+        if n:
+            td_kernels[k] = {"avg_launch_ms": round(tot.value / n, 5), "launches_per_step": n // args.steps}
 
     frames_total = world * nI * nF * args.steps
     value = frames_total / elapsed
@@ -145,12 +178,7 @@ def main():
     if rank == 0:
         roof = None
         if not args.no_profile:
-            per = {}
-            for k in ALG_BYTES_PER_FRAME:
-                tot = C.c_double()
-                n = L.saf_hip_profile_read(k.encode(), C.byref(tot))
-                if n:
-                    per[k] = (tot.value / n, n)
+            per = general_kernels
             if per:
                 dom = max(per, key=lambda k: per[k][0])
                 avg_ms, nl = per[dom]
@@ -189,6 +217,13 @@ def main():
                        "instances_per_gpu": nI, "frames_per_step_per_instance": nF, "frames_per_step_per_gpu": nI * nF,
                        "parallelism": f"independent instances sharded over {world} GPU(s), no collective on the data path"},
             "roofline": roof, "cpu_baseline": cpu,
+            "band_independent_path": {
+                "value": round(frames_total / elapsed_td, 1), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed_td / args.steps, 4),
+                "kernels": td_kernels,
+                "hbm_GBps": round(4 * NCH * FRAME * 4 * (frames_total / world) / elapsed_td / 1e9, 1),
+                "note": "same workload, same outputs (parity 2e-6 vs the oracle): this decoder is identical in all 133 bands, so the library "
+                        "decodes in the time domain and runs afSTFT analysis->synthesis in its transform-free form (saf_hip_ambi_dec_setTimeDomainPath); "
+                        "not the headline value because it does not apply to band-dependent decoding; algorithmic traffic 4 x 131 072 B per frame"},
         }
         if cpu:
             line["speedup_vs_cpu_1core"] = round(value / cpu["value"], 1)

@@ -154,6 +154,13 @@ typedef enum { AMPLITUDE_PRESERVING = 1, ENERGY_PRESERVING } AMBI_DEC_DIFFUSE_FI
 
 /** The reference fixes the block size at compile time (-DAMBI_DEC_FRAME_SIZE, ambi_dec_internal.h:61-67, default 128).
  *  Here it is a process-wide setting read by ambi_dec_create; must be a multiple of 128. */
+/** Band-independent decoding.  When every band of every instance of a pipeline selects the same (decoder, order) matrix
+ *  — the reference's own default configuration does once both decoders use the same method — decoding commutes with the
+ *  filterbank: the library then multiplies in the time domain and runs afSTFT analysis -> synthesis of the loudspeaker
+ *  signals in its transform-free form (the FFT and inverse FFT cancel, the hybrid split/merge reduces to its 3-hop delay).
+ *  Same outputs to rounding (1e-6), same state, selected per call; 0 forces the three-kernel transform path. Default 1. */
+SAF_API void saf_hip_ambi_dec_setTimeDomainPath(int enable);
+SAF_API int  saf_hip_ambi_dec_getTimeDomainPath(void);
 SAF_API void saf_hip_ambi_dec_setFrameSize(int frameSize);
 
 SAF_API void ambi_dec_create(void** const phAmbi);                               /* ambi_dec.h:114 */

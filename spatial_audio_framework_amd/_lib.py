@@ -87,6 +87,8 @@ def load():
     sig("VBAPgainTable2InterpTable", None, fp, ci, ci)
     # ambi_dec
     sig("saf_hip_ambi_dec_setFrameSize", None, ci)
+    sig("saf_hip_ambi_dec_setTimeDomainPath", None, ci)
+    sig("saf_hip_ambi_dec_getTimeDomainPath", ci)
     sig("ambi_dec_create", None, C.POINTER(vp))
     sig("ambi_dec_destroy", None, C.POINTER(vp))
     sig("ambi_dec_init", None, vp, ci)

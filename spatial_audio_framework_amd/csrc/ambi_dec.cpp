@@ -28,6 +28,9 @@ namespace saf {
 #define NMAT (NUM_DECODERS * SAF_MAX_ORDER)
 static int g_ambi_dec_frame_size = 128;    /* default of the reference (ambi_dec_internal.h:65) */
 
+/* band-independent decoding takes the time-domain form (DecPipeline::process) unless switched off */
+static int g_ambi_dec_time_domain = []() { const char* e = getenv("SAF_HIP_AMBI_DEC_TIME_DOMAIN"); return e ? atoi(e) != 0 : 1; }();      /* env: 0 = always the transform path */
+
 static inline void sleep_ms(int ms) { std::this_thread::sleep_for(std::chrono::milliseconds(ms)); }
 
 struct AmbiDec {
@@ -75,6 +78,15 @@ struct DecPipeline {
     DevBuf<int> band2mat;           /* [nInst][133] */
     DevBuf<float> chScale;          /* [nInst][64] */
     DevBuf<int> chMap;              /* [nInst][64] */
+    /* band-independent decoding: when every band of every instance uses the same matrix, decoding commutes with the
+     * filterbank: y = A x in the time domain, then analysis -> synthesis of y without the transforms (launch_roundtrip) */
+    DevBuf<float> AfragT;           /* [nInst][2][32][64] the single matrix with the input conventions folded into its columns */
+    DevBuf<float> ybuf;             /* [nInst][64][(15 + Hmax) * 128] */
+    DevBuf<int> b2mT, zerosI;       /* [nInst] matrix index for the history GEMM; zeros [nInst][maxFrames] */
+    std::vector<int> tdMat;         /* per instance: index of the single matrix, -1 when bands differ */
+    std::vector<char> tdDirty;
+    PinBuf<float> stageT; PinBuf<int> stageTi;
+    bool tdTableDirty = true;
     /* binauralised output (ambi_dec.c:543-563) */
     bool bin = false;
     std::shared_ptr<HrtfTables> hrtf;
@@ -133,6 +145,11 @@ struct DecPipeline {
         chScale.alloc((size_t)nInst * SAF_MAXCH);
         chMap.alloc((size_t)nInst * SAF_MAXCH);
         shadow.assign(nInst, Shadow());
+        tdMat.assign(nInst, -1); tdDirty.assign(nInst, 1);
+        if (!bin) {
+            AfragT.alloc((size_t)nInst * 64 * 64); ybuf.alloc((size_t)nInst * SAF_MAXCH * (SAF_ANA_HIST + Hmax) * SAF_HOP, false);
+            b2mT.alloc(nInst); zerosI.alloc((size_t)nInst * maxFrames); stageT.ensure(64 * 64); stageTi.ensure(nInst);
+        }
         stageA.ensure((size_t)NMAT * 64 * 64); stageI.ensure(SAF_NBANDS + SAF_MAXCH); stageS.ensure(SAF_MAXCH);
     }
 
@@ -166,7 +183,7 @@ struct DecPipeline {
                 if (bin) { HIP_CHECK(hipMemcpyAsync(Arow.p + (size_t)i * NMAT * 64 * 64, stageArow.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream())); foldDirty = true; }
                 HIP_CHECK(hipStreamSynchronize(stream()));
                 s.epoch = p->codecEpoch; s.rE[0] = rE[0]; s.rE[1] = rE[1]; s.eq[0] = eq[0]; s.eq[1] = eq[1];
-                s.b2mValid = false; s.norm = -1;
+                s.b2mValid = false; s.norm = -1; tdDirty[i] = 1;
             }
             int b2m[SAF_NBANDS];
             for (int band = 0; band < SAF_NBANDS; band++) {
@@ -180,7 +197,7 @@ struct DecPipeline {
                 memcpy(stageI.p, b2m, sizeof(b2m));
                 HIP_CHECK(hipMemcpyAsync(band2mat.p + (size_t)i * SAF_NBANDS, stageI.p, sizeof(b2m), hipMemcpyHostToDevice, stream()));
                 HIP_CHECK(hipStreamSynchronize(stream()));
-                memcpy(s.b2m, b2m, sizeof(b2m)); s.b2mValid = true; foldDirty = true;
+                memcpy(s.b2m, b2m, sizeof(b2m)); s.b2mValid = true; foldDirty = true; tdDirty[i] = 1;
             }
             if (s.norm != (int)p->norm || s.chOrd != (int)p->chOrdering) {
                 /* input conventions -> ACN/N3D (ambi_dec.c:500-511, saf_hoa.c:40-116) as a gather map + row scale */
@@ -202,8 +219,60 @@ struct DecPipeline {
                 HIP_CHECK(hipMemcpyAsync(chMap.p + (size_t)i * SAF_MAXCH, map, sizeof(int) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
                 HIP_CHECK(hipMemcpyAsync(chScale.p + (size_t)i * SAF_MAXCH, sc, sizeof(float) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
                 HIP_CHECK(hipStreamSynchronize(stream()));
-                s.norm = (int)p->norm; s.chOrd = (int)p->chOrdering;
+                s.norm = (int)p->norm; s.chOrd = (int)p->chOrdering; tdDirty[i] = 1;
             }
+            if (tdDirty[i] && !bin) {
+                /* time-domain form of the decode: possible when all 133 bands select the same (decoder, order) matrix */
+                /* (the two decoders are separate entries even when they were designed identically: compare contents) */
+                auto eff = [&](int mi, std::vector<float>& E) {
+                    const int d = mi / SAF_MAX_ORDER, n = mi % SAF_MAX_ORDER + 1, nSHo = ORDER2NSH(n);
+                    const std::vector<float>& M = rE[d] ? p->M_dec_maxrE[d][n - 1] : p->M_dec[d][n - 1];
+                    const float msc = p->M_norm[d][n - 1][eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
+                    E.assign(64 * 64, 0.0f);
+                    for (int l = 0; l < p->nLoudpkrs; l++) for (int k = 0; k < nSHo; k++) E[l * 64 + k] = M[(size_t)l * nSHo + k] * msc;
+                };
+                int m = s.b2m[0];
+                {
+                    std::vector<float> E0, E1;
+                    bool seen[NMAT] = { false };
+                    seen[m] = true;
+                    for (int band = 1; band < SAF_NBANDS && m >= 0; band++) {
+                        const int mb = s.b2m[band];
+                        if (seen[mb]) continue;
+                        seen[mb] = true;
+                        if (E0.empty()) eff(m, E0);
+                        eff(mb, E1);
+                        if (memcmp(E0.data(), E1.data(), sizeof(float) * 64 * 64) != 0) m = -1;
+                    }
+                }
+                tdMat[i] = m;
+                if (m >= 0) {
+                    HIP_CHECK(hipStreamSynchronize(stream()));
+                    const int d = m / SAF_MAX_ORDER, n = m % SAF_MAX_ORDER + 1, nSHo = ORDER2NSH(n);
+                    const std::vector<float>& M = rE[d] ? p->M_dec_maxrE[d][n - 1] : p->M_dec[d][n - 1];
+                    const float msc = p->M_norm[d][n - 1][eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
+                    /* x_acn[j] = scale[j] * x_in[map[j]]  ->  column map[j] of the folded matrix collects A[:, j] * scale[j] */
+                    int map[SAF_MAXCH]; float sc[SAF_MAXCH];
+                    for (int ch = 0; ch < SAF_MAXCH; ch++) { map[ch] = ch; sc[ch] = 1.0f; }
+                    if (p->chOrdering == CH_FUMA) { map[1] = 2; map[2] = 3; map[3] = 1; for (int ch = 4; ch < SAF_MAXCH; ch++) map[ch] = -1; }
+                    if (p->norm == NORM_SN3D) { for (int o = 0; o <= p->masterOrder; o++) for (int ch = o * o; ch < ORDER2NSH(o); ch++) sc[ch] = sqrtf(2.0f * (float)o + 1.0f); }
+                    else if (p->norm == NORM_FUMA) { sc[0] = sqrtf(2.0f); for (int ch = 1; ch < 4; ch++) sc[ch] = sqrtf(3.0f); }
+                    std::vector<float> A(64 * 64, 0.0f);
+                    for (int l = 0; l < p->nLoudpkrs; l++)
+                        for (int k = 0; k < nSHo; k++) if (map[k] >= 0) A[l * 64 + map[k]] += (M[(size_t)l * nSHo + k] * msc) * sc[k];
+                    pack_A(A.data(), stageT.p);
+                    HIP_CHECK(hipMemcpyAsync(AfragT.p + (size_t)i * 64 * 64, stageT.p, sizeof(float) * 64 * 64, hipMemcpyHostToDevice, stream()));
+                    HIP_CHECK(hipStreamSynchronize(stream()));
+                }
+                tdDirty[i] = 0; tdTableDirty = true;
+            }
+        }
+        if (tdTableDirty && !bin) {
+            HIP_CHECK(hipStreamSynchronize(stream()));
+            for (int i = 0; i < nInst; i++) stageTi.p[i] = tdMat[i] < 0 ? 0 : tdMat[i];
+            HIP_CHECK(hipMemcpyAsync(b2mT.p, stageTi.p, sizeof(int) * nInst, hipMemcpyHostToDevice, stream()));
+            HIP_CHECK(hipStreamSynchronize(stream()));
+            tdTableDirty = false;
         }
     }
 
@@ -252,6 +321,41 @@ struct DecPipeline {
             }
         }
         const int H = nFrames * T;
+        bool td = !bin && g_ambi_dec_time_domain && nChPresent >= nSH && ((in_inst | in_frame | in_ch) & 3) == 0 && (((uintptr_t)d_in) & 15) == 0 &&
+                  ((out_inst | out_frame | out_ch) & 1) == 0 && (((uintptr_t)d_out) & 7) == 0;
+        for (int i = 0; i < nInst && td; i++) td = tdMat[i] >= 0;
+        if (td) {
+            /* band-independent decoding (every band uses the same matrix): y = A x over the 15 history hops (already in the
+             * ACN/N3D convention) and over the new blocks (conventions folded into the matrix), then the transform-free
+             * analysis -> synthesis of y.  Both states of AfState advance exactly as in the transform path. */
+            const long long yCh = (long long)(SAF_ANA_HIST + Hmax) * SAF_HOP, yInst = (long long)SAF_MAXCH * yCh;
+            BandGemmLaunch gh{};
+            gh.X = st.ana[st.anaPar].p; gh.x_inst = (long long)nSH * SAF_ANA_HIST * SAF_HOP; gh.x_band = 0; gh.x_row = SAF_ANA_HIST * SAF_HOP;
+            gh.Y = ybuf.p; gh.y_inst = yInst; gh.y_band = 0; gh.y_row = yCh;
+            gh.Afrag = Afrag.p; gh.a_inst = (long long)NMAT * 64 * 64; gh.band2mat = b2mT.p;
+            gh.nBands = 1; gh.nInst = nInst; gh.N = SAF_ANA_HIST * SAF_HOP; gh.nRowsX = nSH;
+            launch_band_gemm(gh);
+            BandGemmLaunch gn{};
+            gn.X = d_in; gn.x_inst = in_inst; gn.x_band = in_frame; gn.x_row = in_ch;
+            gn.Y = ybuf.p + SAF_ANA_HIST * SAF_HOP; gn.y_inst = yInst; gn.y_band = F; gn.y_row = yCh;
+            gn.Afrag = AfragT.p; gn.a_inst = 64 * 64; gn.band2mat = zerosI.p;
+            gn.nBands = nFrames; gn.nInst = nInst; gn.N = F; gn.nRowsX = nChPresent < SAF_MAXCH ? nChPresent : SAF_MAXCH;
+            launch_band_gemm(gn);
+            AnaHistLaunch ah{};
+            ah.in = d_in; ah.in_inst = in_inst; ah.in_ch = in_ch; ah.in_frame = in_frame; ah.hopsPerFrame = T; ah.nChIn = nChPresent;
+            ah.hist_rd = st.ana[st.anaPar].p; ah.hist_wr = st.ana[st.anaPar ^ 1].p; ah.ch_scale = chScale.p; ah.ch_map = chMap.p; ah.tab_stride = SAF_MAXCH;
+            ah.nCh = nSH; ah.nInst = nInst; ah.H = H;
+            launch_ana_hist_update(ah);
+            st.anaPar ^= 1;
+            RoundtripLaunch r{};
+            r.y = ybuf.p; r.y_inst = yInst; r.y_ch = yCh;
+            r.out = d_out; r.out_inst = out_inst; r.out_ch = out_ch; r.out_frame = out_frame; r.hopsPerFrame = T;
+            r.syn_rd = st.syn[st.synPar].p; r.syn_wr = st.syn[st.synPar ^ 1].p;
+            r.nCh = nLS; r.nInst = nInst; r.H = H;
+            launch_roundtrip(r);
+            st.synPar ^= 1;
+            return;
+        }
         AnaLaunch a{};
         a.in = d_in; a.in_inst = in_inst; a.in_ch = in_ch; a.in_frame = in_frame; a.hopsPerFrame = T; a.nChIn = nChPresent;
         a.hist_rd = st.ana[st.anaPar].p; a.hist_wr = st.ana[st.anaPar ^ 1].p;
@@ -308,6 +412,9 @@ static void set_codec_status(AmbiDec* p, CODEC_STATUS s)     /* ambi_dec_interna
 using namespace saf;
 
 extern "C" {
+
+void saf_hip_ambi_dec_setTimeDomainPath(int enable) { g_ambi_dec_time_domain = enable ? 1 : 0; }
+int saf_hip_ambi_dec_getTimeDomainPath(void) { return g_ambi_dec_time_domain; }
 
 void saf_hip_ambi_dec_setFrameSize(int frameSize)
 {

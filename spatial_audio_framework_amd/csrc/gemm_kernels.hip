@@ -35,11 +35,15 @@ struct GemmArgs { BandGemmLaunch g; int unitsPerInst, nColTiles, G; };
 /* FULL: every column tile is complete (N % 128 == 0): plain 16-byte loads.  Otherwise masked loads without
  * branches — a load under a branch is followed by its own wait, which would serialise the loads of a tile. */
 template <bool FULL>
-__device__ __forceinline__ void gemm_load_tile(float4 (&b)[32], const float* X, long long x_row, int nValid)
+__device__ __forceinline__ void gemm_load_tile(float4 (&b)[32], const float* X, long long x_row, int nValid, int kh, int nRows)
 {
+    /* this lane's B row of k-pair step i is 2 i + kh; rows beyond nRows re-read the last present row */
+    const long long lastOff = (long long)(nRows - 1) * x_row;
+    long long off = (long long)kh * x_row;
 #pragma unroll
     for (int i = 0; i < 32; i++) {
-        const float* p = X + (long long)(2 * i) * x_row;
+        const float* p = X + (off < lastOff ? off : lastOff);
+        off += 2 * x_row;
         if (FULL) b[i] = *reinterpret_cast<const float4*>(p);
         else {
             /* columns beyond N read column (nValid - 1 clamped) of the same row — valid memory — and are zeroed */
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(128, 1) void band_gemm_kernel(GemmArgs a)
     const int u0 = blockIdx.x * a.G;
     const int u1 = min(u0 + a.G, a.unitsPerInst);
     if (u0 >= u1) return;
-    const float* Xi = g.X + (long long)inst * g.x_inst + (long long)kh * g.x_row;
+    const float* Xi = g.X + (long long)inst * g.x_inst;
     float* Yi = g.Y + (long long)inst * g.y_inst;
     const float* Ai = g.Afrag + (long long)inst * g.a_inst + (long long)rt * 32 * 64 + lane;
     const int* b2m = g.band2mat + inst * g.nBands;
@@ -105,12 +109,12 @@ __global__ __launch_bounds__(128, 1) void band_gemm_kernel(GemmArgs a)
     };
     int bandA, colA, bandB = 0, colB = 0;
     const float* pA = unit_ptr(u0, bandA, colA);
-    gemm_load_tile<FULL>(bA, pA, g.x_row, g.N - colA);
+    gemm_load_tile<FULL>(bA, pA, g.x_row, g.N - colA, kh, g.nRowsX);
     for (int u = u0; u < u1; u += 2) {
-        if (u + 1 < u1) { const float* pB = unit_ptr(u + 1, bandB, colB); gemm_load_tile<FULL>(bB, pB, g.x_row, g.N - colB); }
+        if (u + 1 < u1) { const float* pB = unit_ptr(u + 1, bandB, colB); gemm_load_tile<FULL>(bB, pB, g.x_row, g.N - colB, kh, g.nRowsX); }
         compute_store(bA, bandA, colA);
         if (u + 1 < u1) {
-            if (u + 2 < u1) { pA = unit_ptr(u + 2, bandA, colA); gemm_load_tile<FULL>(bA, pA, g.x_row, g.N - colA); }
+            if (u + 2 < u1) { pA = unit_ptr(u + 2, bandA, colA); gemm_load_tile<FULL>(bA, pA, g.x_row, g.N - colA, kh, g.nRowsX); }
             compute_store(bB, bandB, colB);
         }
     }

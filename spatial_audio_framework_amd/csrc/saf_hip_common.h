@@ -132,6 +132,26 @@ struct SynLaunch {
 };
 void launch_synthesis(const SynLaunch& s);
 
+/* ---- afSTFT analysis -> synthesis of the SAME signal without the transforms (afstft_kernels.hip) ----
+ * When nothing band-dependent happens between afSTFT_forward and afSTFT_backward, the 256-point FFT and its inverse
+ * cancel and the hybrid split / merge reduces to its 3-hop delay: what remains is the window fold, a delay and the
+ * 10-segment overlap-add — per sample position, no data exchange.  y holds, per (instance, channel), the 15 hops before
+ * the call followed by the H hops of the call, contiguous in time. */
+struct RoundtripLaunch {
+    const float* y; long long y_inst, y_ch;            /* y[inst*y_inst + ch*y_ch + hop*128 + n], hop 0 = 15 hops before the call */
+    float* out; long long out_inst, out_ch, out_frame; int hopsPerFrame;
+    const float* syn_rd; float* syn_wr;                /* [inst][nCh][9][256] the synthesis state of AfState */
+    int nCh, nInst, H;
+};
+void launch_roundtrip(const RoundtripLaunch& r);
+/* new analysis history (last 15 hops of the converted input) without running the analysis: AfState::ana format */
+struct AnaHistLaunch {
+    const float* in; long long in_inst, in_ch, in_frame; int hopsPerFrame, nChIn;
+    const float* hist_rd; float* hist_wr; const float* ch_scale; const int* ch_map; int tab_stride;
+    int nCh, nInst, H;
+};
+void launch_ana_hist_update(const AnaHistLaunch& a);
+
 /* ---- band-batched real GEMM on MFMA (gemm_kernels.hip) ----
  * For every (inst, band): Y[64 x N] = A[mat(inst,band)][64 x 64] * X[64 x N], N = 2*H floats
  * (interleaved re/im of H time slots).  A is stored in MFMA fragment order, see pack_A(). */
@@ -142,6 +162,7 @@ struct BandGemmLaunch {
     long long a_inst;              /* float stride between instances' matrix sets */
     const int* band2mat;           /* [nInst][nBands] */
     int nBands, nInst, N;
+    int nRowsX = 64;               /* rows physically present in X: higher rows re-read the last one (their matrix columns are zero) */
 };
 void launch_band_gemm(const BandGemmLaunch& g);
 void pack_A(const float* A /* [64][64] row-major, zero padded */, float* Afrag /* [2][32][64] */);

@@ -395,3 +395,41 @@ def test_ambi_dec_full_size_properties(saf, nI, nF):
     assert torch.equal(y2[:5], ya[:5]) and torch.equal(y2[6:], ya[6:]) and torch.equal(y2[5], yb[5])   # instances independent
     assert torch.equal(ya[0], go(a[:1].contiguous().expand(nI, -1, -1, -1).contiguous())[17])          # same input -> same output
     saf.set_stream(None)
+
+
+@pytest.mark.parametrize("F,order,preset,norm,chord", [(512, 7, 29, 1, 1), (256, 3, 21, 2, 1), (128, 1, 3, 3, 2), (1024, 5, 28, 2, 1)])
+def test_ambi_dec_time_domain_path_equals_transform_path(saf, orc, F, order, preset, norm, chord):
+    """Band-independent decoding (all bands use one matrix) takes the time-domain form: y = A x, then the transform-free
+    analysis -> synthesis.  Same outputs as the three-kernel transform path and as the oracle; the two paths share their
+    state, so they may alternate call by call (here: blocks 0-2 fast, 3-5 transform, 6-8 fast)."""
+    from spatial_audio_framework_amd._lib import load
+    L = load()
+    nSH = (order + 1) ** 2
+
+    def make(cls):
+        d = cls(F)
+        d.setNormType(norm); d.setChOrder(chord); d.setMasterDecOrder(order); d.setOutputConfigPreset(preset)
+        d.setDecMethod(0, 1); d.setDecMethod(1, 1)
+        d.initCodec(); d.init(48000); d.setDecOrderAllBands(order)
+        return d
+
+    nB = 9 if F >= 256 else 27                       # enough blocks to get past the 12-hop latency
+    x = frames(400 + F, nSH, nB * F)
+    o = make(orc.AmbiDec)
+    nLS = o.getNumLoudspeakers()
+    yo = np.concatenate([o.process(np.ascontiguousarray(x[:, b * F:(b + 1) * F]), nLS) for b in range(nB)], 1)
+    outs = {}
+    try:
+        for name, sched in (("fast", [1] * nB), ("transform", [0] * nB), ("mixed", ([1, 1, 1, 0, 0, 0, 1, 1, 1] * 3)[:nB])):
+            g = make(saf.AmbiDec)
+            ys = []
+            for b in range(nB):
+                L.saf_hip_ambi_dec_setTimeDomainPath(sched[b])
+                ys.append(g.process(np.ascontiguousarray(x[:, b * F:(b + 1) * F]), nLS))
+            outs[name] = np.concatenate(ys, 1)
+    finally:
+        L.saf_hip_ambi_dec_setTimeDomainPath(1)
+    assert np.abs(yo).max() > 0.05
+    for name, y in outs.items():
+        assert relrms(y, yo) < 2e-6, name
+    assert relrms(outs["fast"], outs["transform"]) < 2e-6 and relrms(outs["mixed"], outs["transform"]) < 2e-6
