@@ -16,7 +16,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 sys.path.insert(0, str(HERE.parent))
 sys.path.insert(0, str(HERE.parent.parent))
-from util import frames  # noqa: E402
+from util import frames, synth_hrirs  # noqa: E402
 
 
 def ambi_dec_cfg(cls, F, order, preset, m0, m1, low_order=None):
@@ -57,7 +57,68 @@ def generate(O):
     xc = frames(303, 3, 5 * 64)
     out["matrixconv_small"] = {"out": np.concatenate([mc.apply(xc[:, i * 64:(i + 1) * 64]) for i in range(5)], 1)}
     out["ambi_enc_small"] = {"out": ambi_enc_scenario(O.AmbiEnc)}
+    out["panner_small"] = {"out": panner_scenario(O.Panner)}
+    out["conv_small"] = conv_scenarios(O.MultiConv, O.TVConv)
+    out["ambi_dec_bin_small"] = {"out": ambi_dec_bin_scenario(O.AmbiDec)}
+    out["pmaps_small"] = pmaps_scenario(O)
     return out
+
+
+def panner_scenario(cls, F=128, nB=16):
+    """7 sources (first directions of SphCovering-64) -> 5.x, DTT 0.3, a rotation from block 4 on, source 2 moved at block 8"""
+    p = cls(F)
+    p.setOutputConfigPreset(3); p.setInputConfigPreset(30); p.setNumSources(7)
+    p.initCodec(); p.init(48000); p.setDTT(0.3); p.initCodec()
+    x = frames(505, 7, nB * F)
+    ys = []
+    for b in range(nB):
+        if b == 4:
+            p.setYaw(25.0); p.setPitch(-10.0)
+        if b == 8:
+            p.setSourceAzi_deg(2, 123.0); p.setSourceElev_deg(2, 33.0)
+        ys.append(p.process(x[:, b * F:(b + 1) * F], 5))
+    return np.concatenate(ys, 1)
+
+
+def conv_scenarios(MultiConv, TVConv):
+    """multiConv: 4 channels x 150 taps, hop 64, both modes; TVConv: 1 -> 2 channels, 3 IR sets of 150 taps, index switches"""
+    rng = np.random.default_rng(6)
+    H = (rng.normal(size=(4, 150)) / 8).astype(np.float32)
+    x = frames(606, 4, 8 * 64)
+    res = {}
+    for part in (1, 0):
+        mc = MultiConv(64, H, part)
+        res[f"multi_part{part}"] = np.concatenate([mc.apply(np.ascontiguousarray(x[:, b * 64:(b + 1) * 64])) for b in range(8)], 1)
+    Ht = (rng.normal(size=(3, 2, 150)) / 8).astype(np.float32)
+    tv = TVConv(64, Ht, 1)
+    idx = [1, 1, 2, 2, 0, 1, 1, 1]
+    res["tv"] = np.concatenate([tv.apply(x[0, b * 64:(b + 1) * 64], idx[b]) for b in range(8)], 1)
+    return res
+
+
+def ambi_dec_bin_scenario(cls, F=128, nB=20):
+    """order 2 -> t-design(12) -> 2 ears, SAD, HRIR pre-processing on, synthetic 836-direction HRIR set (tests/util.py)"""
+    h, d = synth_hrirs()
+    a = cls(F)
+    a.setHRIRs(h, d, 48000)
+    a.setNormType(1); a.setChOrder(1); a.setMasterDecOrder(2); a.setOutputConfigPreset(20)
+    a.setDecMethod(0, 1); a.setDecMethod(1, 1); a.setBinauraliseLSflag(1)
+    a.init(48000); a.initCodec(); a.setDecOrderAllBands(2)
+    x = frames(707, 9, nB * F)
+    return np.concatenate([a.process(x[:, b * F:(b + 1) * F], 2) for b in range(nB)], 1)
+
+
+def pmaps_scenario(O):
+    """order-3 covariance of two plane waves + noise on the 240-point t-design: MVDR map, 1/MUSIC, 1/MinNorm, CroPaC map"""
+    rng = np.random.default_rng(7)
+    order, nSH = 3, 16
+    grid = O.table("Tdesign_degree_21_dirs_deg")
+    Yg = (O.getRSH(order, grid) / nSH).astype(np.float32)
+    s = rng.normal(size=(2, 3000)) + 1j * rng.normal(size=(2, 3000))
+    xs = O.getRSH(order, grid[[139, 204]]) @ s + 0.02 * (rng.normal(size=(nSH, 3000)) + 1j * rng.normal(size=(nSH, 3000)))
+    Cx = (xs @ xs.conj().T / 3000).astype(np.complex64)
+    return {"Cx": Cx, "mvdr": O.generateMVDRmap(order, Cx, Yg), "cropac": O.generateCroPaCLCMVmap(order, Cx, Yg),
+            "inv_music": 1.0 / O.generateMUSICmap(order, Cx, Yg, 2), "inv_minnorm": 1.0 / O.generateMinNormMap(order, Cx, Yg, 2)}
 
 
 def ambi_enc_scenario(cls, F=256, nFrames=8):
