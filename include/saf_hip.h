@@ -523,6 +523,45 @@ SAF_API void saf_hip_panner_process_dev(void* const hPan, const float* d_in, lon
 /** Read-back for parity checks: G_src as [133][64][64] (band, source, loudspeaker), panner_internal.h:99. */
 SAF_API void saf_hip_panner_getGains(void* const hPan, float* G);
 
+/* ========================================================================== */
+/*      matrixconv / multiconv example operators (sample-wise FIFO around the convolvers)  */
+/* ========================================================================== */
+SAF_API void matrixconv_create(void** const phMCnv);                                                                  /* matrixconv.h:53 */
+SAF_API void matrixconv_destroy(void** const phMCnv);                                                                 /* matrixconv.h:60 */
+SAF_API void matrixconv_init(void* const hMCnv, int samplerate, int hostBlockSize);                                   /* matrixconv.h:69 */
+SAF_API void matrixconv_process(void* const hMCnv, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* matrixconv.h:83 */
+SAF_API void matrixconv_refreshParams(void* const hMCnv);                                                             /* matrixconv.h:99 */
+SAF_API void matrixconv_checkReInit(void* const hMCnv);                                                               /* matrixconv.h:104 */
+SAF_API void matrixconv_setFilters(void* const hMCnv, const float** H, int numChannels, int numSamples, int sampleRate); /* matrixconv.h:124 */
+SAF_API void matrixconv_setEnablePart(void* const hMCnv, int newState);                                               /* matrixconv.h:131 */
+SAF_API void matrixconv_setNumInputChannels(void* const hMCnv, int newValue);                                         /* matrixconv.h:141 */
+SAF_API int  matrixconv_getEnablePart(void* const hMCnv);                                                             /* matrixconv.h:158 */
+SAF_API int  matrixconv_getNumInputChannels(void* const hMCnv);                                                       /* matrixconv.h:161 */
+SAF_API int  matrixconv_getNumOutputChannels(void* const hMCnv);                                                      /* matrixconv.h:167 */
+SAF_API int  matrixconv_getHostBlockSize(void* const hMCnv);                                                          /* matrixconv.h:170 */
+SAF_API int  matrixconv_getNfilters(void* const hMCnv);                                                               /* matrixconv.h:176 */
+SAF_API int  matrixconv_getFilterLength(void* const hMCnv);                                                           /* matrixconv.h:179 */
+SAF_API int  matrixconv_getFilterFs(void* const hMCnv);                                                               /* matrixconv.h:182 */
+SAF_API int  matrixconv_getHostFs(void* const hMCnv);                                                                 /* matrixconv.h:185 */
+SAF_API int  matrixconv_getProcessingDelay(void* const hMCnv);                                                        /* matrixconv.h:191 */
+SAF_API void multiconv_create(void** const phMCnv);                                                                   /* multiconv.h:53 */
+SAF_API void multiconv_destroy(void** const phMCnv);                                                                  /* multiconv.h:60 */
+SAF_API void multiconv_init(void* const hMCnv, int samplerate, int hostBlockSize);                                    /* multiconv.h:69 */
+SAF_API void multiconv_process(void* const hMCnv, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* multiconv.h:83 */
+SAF_API void multiconv_refreshParams(void* const hMCnv);                                                              /* multiconv.h:99 */
+SAF_API void multiconv_checkReInit(void* const hMCnv);                                                                /* multiconv.h:104 */
+SAF_API void multiconv_setFilters(void* const hMCnv, const float** H, int numChannels, int numSamples, int sampleRate); /* multiconv.h:117 */
+SAF_API void multiconv_setEnablePart(void* const hMCnv, int newState);                                                /* multiconv.h:124 */
+SAF_API void multiconv_setNumChannels(void* const hMCnv, int newValue);                                               /* multiconv.h:127 */
+SAF_API int  multiconv_getEnablePart(void* const hMCnv);                                                              /* multiconv.h:144 */
+SAF_API int  multiconv_getNumChannels(void* const hMCnv);                                                             /* multiconv.h:147 */
+SAF_API int  multiconv_getHostBlockSize(void* const hMCnv);                                                           /* multiconv.h:150 */
+SAF_API int  multiconv_getNfilters(void* const hMCnv);                                                                /* multiconv.h:153 */
+SAF_API int  multiconv_getFilterLength(void* const hMCnv);                                                            /* multiconv.h:156 */
+SAF_API int  multiconv_getFilterFs(void* const hMCnv);                                                                /* multiconv.h:159 */
+SAF_API int  multiconv_getHostFs(void* const hMCnv);                                                                  /* multiconv.h:162 */
+SAF_API int  multiconv_getProcessingDelay(void* const hMCnv);                                                         /* multiconv.h:168 */
+
 #ifdef __cplusplus
 }
 #endif

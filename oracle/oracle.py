@@ -358,6 +358,32 @@ class TVConv:
             lib().orc_TVConv_destroy(C.byref(self.h))
 
 
+class ConvExample:
+    """matrixconv (matrix=1) / multiconv (matrix=0) example operators"""
+
+    def __init__(self, matrix):
+        self.h = vp()
+        lib().orc_convex_create(C.byref(self.h), matrix)
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_convex_" + name)
+        return lambda *a: fn(self.h, *a)
+
+    def setFilters(self, H, fs=48000):
+        H = np.ascontiguousarray(H, np.float32)
+        lib().orc_convex_setFilters(self.h, fptr(H), H.shape[0], H.shape[1])
+
+    def process(self, x, nOut):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((nOut, x.shape[1]), np.float32)
+        lib().orc_convex_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, x.shape[1])
+        return y
+
+    def __del__(self):
+        if self.h:
+            lib().orc_convex_destroy(C.byref(self.h))
+
+
 def binaural_mac(inTF, hrtf, nSrc, scale):
     """inTF [nBands][nSrcStride][T] c64, hrtf [nSrc][nBands][2] c64 -> [nBands][2][T]."""
     inTF = np.ascontiguousarray(inTF, np.complex64)

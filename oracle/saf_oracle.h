@@ -195,6 +195,17 @@ const orc_cpx* orc_powermap_getCx(void* h);          /* [133][64*64], row stride
 const float* orc_powermap_getRawPmap(void* h);       /* [grid_nDirs] after temporal smoothing */
 int  orc_powermap_getGridNDirs(void* h);
 
+/* ---- matrixconv / multiconv example operators (examples/src/matrixconv, examples/src/multiconv): FIFO around the convolvers ---- */
+void orc_convex_create(void** ph, int matrix /* 1: matrixconv, 0: multiconv */);
+void orc_convex_destroy(void** ph);
+void orc_convex_init(void* h, int sampleRate, int hostBlockSize);
+void orc_convex_setFilters(void* h, const float* H /* [numChannels][numSamples] */, int numChannels, int numSamples);
+void orc_convex_setEnablePart(void* h, int s);
+void orc_convex_setNumInputChannels(void* h, int n);       /* multiconv: setNumChannels */
+int  orc_convex_getProcessingDelay(void* h);
+int  orc_convex_getFilterLength(void* h);
+void orc_convex_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
+
 /* ---- adaptive / sub-space activity maps (saf_sh.c:1586-1858); Y_grid is the REAL [nSH][G] matrix (the reference passes it as complex with zero imaginary part) ---- */
 void orc_generateMVDRmap(int order, const orc_cpx* Cx, const float* Y_grid, int G, float regPar, float* pmap, orc_cpx* w_MVDR_out /* [nSH][G] or NULL */);
 void orc_generateCroPaCLCMVmap(int order, const orc_cpx* Cx, const float* Y_grid, int G, float regPar, float lambda, float* pmap);

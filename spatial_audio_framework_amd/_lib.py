@@ -224,6 +224,17 @@ def load():
     sig("panner_getProgressBarText", None, vp, C.c_char_p)
     sig("saf_hip_panner_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci)
     sig("saf_hip_panner_getGains", None, vp, fp)
+    # matrixconv / multiconv example operators
+    for pre, nin in (("matrixconv", "setNumInputChannels"), ("multiconv", "setNumChannels")):
+        sig(pre + "_create", None, C.POINTER(vp)); sig(pre + "_destroy", None, C.POINTER(vp))
+        sig(pre + "_init", None, vp, ci, ci)
+        sig(pre + "_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+        sig(pre + "_refreshParams", None, vp); sig(pre + "_checkReInit", None, vp)
+        sig(pre + "_setFilters", None, vp, C.POINTER(fp), ci, ci, ci)
+        sig(pre + "_setEnablePart", None, vp, ci); sig(pre + "_" + nin, None, vp, ci)
+        for g in ("getEnablePart", "getHostBlockSize", "getNfilters", "getFilterLength", "getFilterFs", "getHostFs", "getProcessingDelay", nin.replace("set", "get")):
+            sig(pre + "_" + g, ci, vp)
+    sig("matrixconv_getNumOutputChannels", ci, vp)
     # activity-map generators
     sig("generatePWDmap", None, ci, vp, vp, ci, fp)
     sig("generateMVDRmap", None, ci, vp, vp, ci, cf, fp, vp)

@@ -401,6 +401,37 @@ class TVConv:
             self.L.saf_TVConv_destroy(C.byref(self.h))
 
 
+class ConvExample:
+    """matrixconv (matrix=1, examples/include/matrixconv.h) / multiconv (matrix=0, multiconv.h) example operators"""
+
+    def __init__(self, matrix):
+        self.L = load()
+        self.pre = "matrixconv" if matrix else "multiconv"
+        self.h = vp()
+        getattr(self.L, self.pre + "_create")(C.byref(self.h))
+
+    def __getattr__(self, name):
+        if name == "setNumInputChannels" and self.pre == "multiconv":
+            name = "setNumChannels"
+        fn = getattr(load(), self.pre + "_" + name)
+        return lambda *a: fn(self.h, *a)
+
+    def setFilters(self, H, fs=48000):
+        H = np.ascontiguousarray(H, np.float32)
+        rows = (C.POINTER(C.c_float) * H.shape[0])(*[_f(H[i]) for i in range(H.shape[0])])
+        getattr(self.L, self.pre + "_setFilters")(self.h, rows, H.shape[0], H.shape[1], fs)
+
+    def process(self, x, nOut):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.full((nOut, x.shape[1]), np.nan, np.float32)
+        getattr(self.L, self.pre + "_process")(self.h, _rows(x), _rows(y), x.shape[0], nOut, x.shape[1])
+        return y
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.L, self.pre + "_destroy")(C.byref(self.h))
+
+
 # ---------------------------------------------------------------- HRIR processing / binauraliser
 def estimateITDs(hrirs, fs):
     hrirs = np.ascontiguousarray(hrirs, np.float32)

@@ -155,3 +155,27 @@ def test_tvconv_batched_device_entry(saf, orc):
     yo = np.concatenate([o.apply(x[b * hop:(b + 1) * hop], idx[b]) for b in range(2 * nB)], 1)
     assert relrms(d_out.cpu().numpy(), yo) < TOL
     saf.set_stream(None)
+
+
+@pytest.mark.parametrize("matrix", [1, 0])
+def test_conv_example_wrappers_vs_oracle(saf, orc, matrix):
+    """matrixconv / multiconv example operators (examples/src/matrixconv, multiconv): sample-wise FIFO, host block clamped to
+    512..8192, output one block late, ragged call sizes, a re-init (partitioning switched) mid-stream."""
+    rng = np.random.default_rng(4 + matrix)
+    nIn, nOut, L = (3, 2, 300) if matrix else (5, 5, 700)
+    H = (rng.normal(size=(nOut, nIn * L)) / 8).astype(np.float32) if matrix else (rng.normal(size=(nIn, L)) / 8).astype(np.float32)
+    g, o = saf.ConvExample(matrix), orc.ConvExample(matrix)
+    for c in (g, o):
+        c.setNumInputChannels(nIn); c.setFilters(H); c.setEnablePart(1); c.init(48000, 600)
+    assert g.getProcessingDelay() == o.getProcessingDelay() == 600 and g.getFilterLength() == L
+    x = frames(70 + matrix, nIn, 6000)
+    pos, yg, yo = 0, [], []
+    for n in (100, 500, 600, 1234, 66, 900, 600):
+        if pos == 2500:
+            for c in (g, o):
+                c.setEnablePart(0)
+        blk = np.ascontiguousarray(x[:, pos:pos + n]); pos += n
+        yg.append(g.process(blk, nOut + 1)); yo.append(o.process(blk, nOut + 1))
+    yg, yo = np.concatenate(yg, 1), np.concatenate(yo, 1)
+    assert np.all(yg[nOut] == 0) and np.abs(yo).max() > 0.1
+    assert relrms(yg, yo) < TOL
