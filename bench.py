@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--frames-per-call", type=int, default=int(os.environ.get("SAF_BENCH_FRAMES", 64)), help="consecutive blocks per instance per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-band-independent", action="store_true", help="skip the second timed region (band-independent shortcut); used by the PMC passes")
     args = ap.parse_args()
 
     import torch
@@ -150,8 +151,9 @@ def main():
             general_kernels[k] = (tot.value / n, n)
 
     # ---- the same steps through the band-independent shortcut (time-domain GEMM + transform-free filterbank round trip)
+    elapsed_td, td_kernels = None, {}
     L.saf_hip_ambi_dec_setTimeDomainPath(1)
-    for i in range(max(2, args.warmup)):
+    for i in range(0 if args.no_band_independent else max(2, args.warmup)):
         step(i)
     torch.cuda.synchronize()
     L.saf_hip_profile_reset()
@@ -159,14 +161,13 @@ def main():
     P.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(0 if args.no_band_independent else args.steps):
         step(i)
     torch.cuda.synchronize()
     P.barrier()
     elapsed_td = P.max_over_ranks(time.perf_counter() - t1, device=dev)
     L.saf_hip_profile_enable(0)
-    td_kernels = {}
-    for k in ("band_gemm", "afstft_roundtrip"):
+    for k in (() if args.no_band_independent else ("band_gemm", "afstft_roundtrip")):
         tot = C.c_double()
         n = L.saf_hip_profile_read(k.encode(), C.byref(tot))
         if n:
@@ -217,7 +218,7 @@ def main():
                        "instances_per_gpu": nI, "frames_per_step_per_instance": nF, "frames_per_step_per_gpu": nI * nF,
                        "parallelism": f"independent instances sharded over {world} GPU(s), no collective on the data path"},
             "roofline": roof, "cpu_baseline": cpu,
-            "band_independent_path": {
+            "band_independent_path": None if args.no_band_independent else {
                 "value": round(frames_total / elapsed_td, 1), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed_td / args.steps, 4),
                 "kernels": td_kernels,
                 "hbm_GBps": round(4 * NCH * FRAME * 4 * (frames_total / world) / elapsed_td / 1e9, 1),

@@ -619,25 +619,26 @@ __global__ __launch_bounds__(256) void afstft_roundtrip_kernel(RtArgs g)
 }
 
 struct AhArgs { AnaHistLaunch a; };
-/* grid (ceil(nCh * 15 * 128 / 256), nInst): hist_wr[ch][row] = hop (H - 15 + row) of [old history | converted input] */
-__global__ __launch_bounds__(256) void ana_hist_update_kernel(AhArgs g)
+/* grid (nCh, nInst), 15 x 32 threads: hist_wr[ch][row] = hop (H - 15 + row) of [old history | converted input]; 16-byte accesses */
+__global__ __launch_bounds__(SAF_ANA_HIST * 32) void ana_hist_update_kernel(AhArgs g)
 {
     const AnaHistLaunch& a = g.a;
-    const int e = blockIdx.x * 256 + threadIdx.x, inst = blockIdx.y;
-    const int n = e & 127, row = (e >> 7) % SAF_ANA_HIST, ch = (e >> 7) / SAF_ANA_HIST;
-    if (ch >= a.nCh) return;
+    const int ch = blockIdx.x, inst = blockIdx.y;
+    const int row = threadIdx.x >> 5, n = 4 * (threadIdx.x & 31);
     const int tabStride = a.tab_stride ? a.tab_stride : a.nCh;
     const int h = a.H - SAF_ANA_HIST + row;
-    float v;
-    if (h < 0) v = a.hist_rd[((long long)inst * a.nCh + ch) * (SAF_ANA_HIST * SAF_HOP) + (SAF_ANA_HIST + h) * SAF_HOP + n];
+    float4 v;
+    if (h < 0) v = *reinterpret_cast<const float4*>(a.hist_rd + ((long long)inst * a.nCh + ch) * (SAF_ANA_HIST * SAF_HOP) + (SAF_ANA_HIST + h) * SAF_HOP + n);
     else {
         const int src = a.ch_map ? a.ch_map[inst * tabStride + ch] : ch;
         const bool valid = src >= 0 && src < a.nChIn;
         const float sc = valid ? (a.ch_scale ? a.ch_scale[inst * tabStride + ch] : 1.0f) : 0.0f;
         const int fr = h / a.hopsPerFrame, sb = h - fr * a.hopsPerFrame;
-        v = a.in[(long long)inst * a.in_inst + (long long)fr * a.in_frame + (long long)(valid ? src : 0) * a.in_ch + sb * SAF_HOP + n] * sc;
+        const float* p = a.in + (long long)inst * a.in_inst + (long long)fr * a.in_frame + (long long)(valid ? src : 0) * a.in_ch + sb * SAF_HOP + n;
+        v = a.vec4 ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
+        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
     }
-    a.hist_wr[((long long)inst * a.nCh + ch) * (SAF_ANA_HIST * SAF_HOP) + row * SAF_HOP + n] = v;
+    *reinterpret_cast<float4*>(a.hist_wr + ((long long)inst * a.nCh + ch) * (SAF_ANA_HIST * SAF_HOP) + row * SAF_HOP + n) = v;
 }
 
 /* ========================================================================== */
@@ -745,7 +746,8 @@ void launch_ana_hist_update(const AnaHistLaunch& a)
 {
     if (a.nCh <= 0 || a.nInst <= 0 || !a.hist_wr) return;
     AhArgs g; g.a = a;
-    hipLaunchKernelGGL(ana_hist_update_kernel, dim3((a.nCh * SAF_ANA_HIST * 128 + 255) / 256, a.nInst), dim3(256), 0, stream(), g);
+    g.a.vec4 = ((a.in_inst | a.in_ch | a.in_frame) & 3) == 0 && (((uintptr_t)a.in) & 15) == 0;
+    hipLaunchKernelGGL(ana_hist_update_kernel, dim3(a.nCh, a.nInst), dim3(SAF_ANA_HIST * 32), 0, stream(), g);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -149,6 +149,7 @@ struct AnaHistLaunch {
     const float* in; long long in_inst, in_ch, in_frame; int hopsPerFrame, nChIn;
     const float* hist_rd; float* hist_wr; const float* ch_scale; const int* ch_map; int tab_stride;
     int nCh, nInst, H;
+    bool vec4 = false;          /* set by the launcher: input strides / base allow 16-byte loads */
 };
 void launch_ana_hist_update(const AnaHistLaunch& a);
 
