@@ -562,6 +562,16 @@ SAF_API int  multiconv_getFilterFs(void* const hMCnv);                          
 SAF_API int  multiconv_getHostFs(void* const hMCnv);                                                                  /* multiconv.h:162 */
 SAF_API int  multiconv_getProcessingDelay(void* const hMCnv);                                                         /* multiconv.h:168 */
 
+/* ========================================================================== */
+/*      real FFT object (saf_utility_fft.h / saf_utility_fft.c:531-753)        */
+/* ========================================================================== */
+/* N even, N/2 = 2^a 3^b 5^c (x primes <= 31): every size of test__saf_rfft.  forward: unscaled, N/2+1 bins;
+ * backward: scaled 1/N, imaginary parts of DC and Nyquist ignored.  Host pointers. */
+SAF_API void saf_rfft_create(void** const phFFT, int N);                                   /* saf_utility_fft.h (saf_utility_fft.c:531) */
+SAF_API void saf_rfft_destroy(void** const phFFT);                                         /* saf_utility_fft.c:642 */
+SAF_API void saf_rfft_forward(void* const hFFT, float* inputTD, float_complex* outputFD);  /* saf_utility_fft.c:690 */
+SAF_API void saf_rfft_backward(void* const hFFT, float_complex* inputFD, float* outputTD); /* saf_utility_fft.c:728 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,6 +235,11 @@ def load():
         for g in ("getEnablePart", "getHostBlockSize", "getNfilters", "getFilterLength", "getFilterFs", "getHostFs", "getProcessingDelay", nin.replace("set", "get")):
             sig(pre + "_" + g, ci, vp)
     sig("matrixconv_getNumOutputChannels", ci, vp)
+    # real FFT object
+    sig("saf_rfft_create", None, C.POINTER(vp), ci)
+    sig("saf_rfft_destroy", None, C.POINTER(vp))
+    sig("saf_rfft_forward", None, vp, fp, vp)
+    sig("saf_rfft_backward", None, vp, vp, fp)
     # activity-map generators
     sig("generatePWDmap", None, ci, vp, vp, ci, fp)
     sig("generateMVDRmap", None, ci, vp, vp, ci, cf, fp, vp)

@@ -432,6 +432,26 @@ class ConvExample:
             getattr(self.L, self.pre + "_destroy")(C.byref(self.h))
 
 
+class Rfft:
+    """saf_rfft_* (saf_utility_fft.c:531-753)"""
+
+    def __init__(self, N):
+        self.L = load(); self.N = N; self.h = vp()
+        self.L.saf_rfft_create(C.byref(self.h), N)
+
+    def forward(self, x):
+        x = np.ascontiguousarray(x, np.float32); X = np.zeros(self.N // 2 + 1, np.complex64)
+        self.L.saf_rfft_forward(self.h, _f(x), X.ctypes.data_as(vp)); return X
+
+    def backward(self, X):
+        X = np.ascontiguousarray(X, np.complex64); x = np.zeros(self.N, np.float32)
+        self.L.saf_rfft_backward(self.h, X.ctypes.data_as(vp), _f(x)); return x
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.saf_rfft_destroy(C.byref(self.h))
+
+
 # ---------------------------------------------------------------- HRIR processing / binauraliser
 def estimateITDs(hrirs, fs):
     hrirs = np.ascontiguousarray(hrirs, np.float32)

@@ -433,3 +433,26 @@ def test_ambi_dec_time_domain_path_equals_transform_path(saf, orc, F, order, pre
     for name, y in outs.items():
         assert relrms(y, yo) < 2e-6, name
     assert relrms(outs["fast"], outs["transform"]) < 2e-6 and relrms(outs["mixed"], outs["transform"]) < 2e-6
+
+
+# fftSizesToTest of test__saf_rfft (test/src/test__utilities_module.c:382-384)
+SAF_RFFT_SIZES = [16, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 1048576,
+                  80, 160, 320, 640, 1280, 240, 480, 960, 1920, 3840, 7680, 15360, 30720]
+
+
+@pytest.mark.parametrize("N", SAF_RFFT_SIZES + [2, 4, 6, 14, 98, 186])
+def test_saf_rfft_reference_test_on_gpu(saf, orc, N):
+    """The reference's own test__saf_rfft (test/src/test__utilities_module.c:374-412) against the GPU object:
+    backward(forward(x)) == x within 1e-5 for every size it lists; plus the spectrum against the oracle (itself checked
+    against the reference's KissFFT in test_oracle_cpu.py) and a few sizes with factors 7 and 31."""
+    x = frames(N, 1, N)[0]
+    f = saf.Rfft(N)
+    X = f.forward(x)
+    assert maxabs(f.backward(X), x) <= 1e-5
+    ref = np.fft.rfft(x.astype(np.float64))
+    assert np.abs(X - ref).max() <= 3e-6 * np.abs(ref).max()
+    if N <= 65536:
+        o = orc.RFFT(N)
+        assert np.abs(X - o.forward(x)).max() <= 3e-6 * np.abs(ref).max()
+        Xr = (np.random.default_rng(N).normal(size=N // 2 + 1) + 1j * np.random.default_rng(N + 1).normal(size=N // 2 + 1)).astype(np.complex64)
+        assert maxabs(f.backward(Xr), o.backward(Xr)) <= 1e-5      # includes non-zero Im at DC / Nyquist: ignored by both
