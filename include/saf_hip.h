@@ -464,6 +464,13 @@ SAF_API void generateMVDRmap(int order, float_complex* Cx, float_complex* Y_grid
 SAF_API void generateCroPaCLCMVmap(int order, float_complex* Cx, float_complex* Y_grid, int nGrid_dirs, float regPar, float lambda, float* pmap);              /* saf_sh.c:1650 */
 SAF_API void generateMUSICmap(int order, float_complex* Cx, float_complex* Y_grid, int nSources, int nGrid_dirs, int logScaleFlag, float* pmap);               /* saf_sh.c:1754 */
 SAF_API void generateMinNormMap(int order, float_complex* Cx, float_complex* Y_grid, int nSources, int nGrid_dirs, int logScaleFlag, float* pmap);             /* saf_sh.c:1801 */
+/* Scanning objects with peak search (saf_sh.h; saf_sh.c:1042-1306): steering vectors = orthonormal real SH of the grid. */
+SAF_API void sphPWD_create(void** const phPWD, int order, float* grid_dirs_deg, int nDirs);                      /* saf_sh.c:1042 */
+SAF_API void sphPWD_destroy(void** const phPWD);                                                                 /* saf_sh.c:1088 */
+SAF_API void sphPWD_compute(void* const hPWD, float_complex* Cx, int nSrcs, float* P_map, int* peak_inds);        /* saf_sh.c:1109 */
+SAF_API void sphMUSIC_create(void** const phMUSIC, int order, float* grid_dirs_deg, int nDirs);                  /* saf_sh.c:1172 */
+SAF_API void sphMUSIC_destroy(void** const phMUSIC);                                                             /* saf_sh.c:1220 */
+SAF_API void sphMUSIC_compute(void* const hMUSIC, float_complex* Vn, int nSrcs, float* P_music, int* peak_inds);  /* saf_sh.c:1243 */
 
 /* ========================================================================== */
 /*      panner (examples/include/panner.h:83-325) + getPvalues                 */

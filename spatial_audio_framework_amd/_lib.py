@@ -246,6 +246,10 @@ def load():
     sig("generateCroPaCLCMVmap", None, ci, vp, vp, ci, cf, cf, fp)
     sig("generateMUSICmap", None, ci, vp, vp, ci, ci, ci, fp)
     sig("generateMinNormMap", None, ci, vp, vp, ci, ci, ci, fp)
+    for n in ("sphPWD", "sphMUSIC"):
+        sig(n + "_create", None, C.POINTER(vp), ci, fp, ci)
+        sig(n + "_destroy", None, C.POINTER(vp))
+        sig(n + "_compute", None, vp, vp, ci, fp, C.POINTER(ci))
     # powermap
     sig("saf_hip_powermap_setFrameSize", None, ci)
     sig("powermap_create", None, C.POINTER(vp))

@@ -608,6 +608,26 @@ def generateMinNormMap(order, Cx, Y_grid, nSources, logScale=0):
     load().generateMinNormMap(order, Cx.ctypes.data_as(vp), Y.ctypes.data_as(vp), nSources, G, logScale, _f(pm)); return pm
 
 
+class SphScan:
+    """sphPWD (kind="PWD", input Cx) / sphMUSIC (kind="MUSIC", input Vn) scanning objects (saf_sh.c:1042-1306)"""
+
+    def __init__(self, kind, order, grid_dirs_deg):
+        self.L = load(); self.kind = "sph" + kind; self.h = vp()
+        g = np.ascontiguousarray(grid_dirs_deg, np.float32)
+        self.G = g.shape[0]
+        getattr(self.L, self.kind + "_create")(C.byref(self.h), order, _f(g), self.G)
+
+    def compute(self, M, nSrcs):
+        M = np.ascontiguousarray(M, np.complex64)
+        P = np.zeros(self.G, np.float32); pk = (C.c_int * nSrcs)()
+        getattr(self.L, self.kind + "_compute")(self.h, M.ctypes.data_as(vp), nSrcs, _f(P), pk)
+        return P, list(pk)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            getattr(self.L, self.kind + "_destroy")(C.byref(self.h))
+
+
 # ---------------------------------------------------------------- powermap
 class Powermap:
     """examples/include/powermap.h.  `frameSize` plays the role of -DPOWERMAP_FRAME_SIZE."""

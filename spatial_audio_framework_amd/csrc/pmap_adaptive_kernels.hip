@@ -382,4 +382,12 @@ void launch_adaptive_map(const AdaptMapLaunch& l)
     HIP_CHECK(hipGetLastError());
 }
 
+void launch_subspace_map(const AdaptMapLaunch& l)
+{
+    AdArgs a; a.l = l;
+    KernelTimer kt("adaptive_map");
+    hipLaunchKernelGGL(subspace_kernel, dim3((l.G + 255) / 256), dim3(256), 0, stream(), a);
+    HIP_CHECK(hipGetLastError());
+}
+
 }  // namespace saf

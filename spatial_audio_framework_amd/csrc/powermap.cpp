@@ -434,4 +434,85 @@ void generateMUSICmap(int order, float_complex* Cx, float_complex* Y_grid, int n
 void generateMinNormMap(int order, float_complex* Cx, float_complex* Y_grid, int nSources, int nGrid_dirs, int logScaleFlag, float* pmap)
 { run_generate_map(logScaleFlag ? 7 : 6, order, Cx, Y_grid, nGrid_dirs, 0.f, 0.f, nSources, pmap, nullptr); }
 
+/* ---- sphPWD / sphMUSIC objects (saf_sh.h; saf_sh.c:1042-1306): steering vectors = orthonormal real SH of the scanning grid,
+ *      map on the GPU, the von-Mises-masked peak search (:1139-1169, :1275-1305) on the host ---- */
+struct SphScan {
+    int order, nSH, nDirs;
+    std::vector<float> svecs;       /* [nSH][nDirs] */
+    std::vector<float> xyz;         /* [nDirs][3] */
+    std::vector<float> pSpec;
+};
+static SphScan* sph_scan_create(int order, const float* grid_dirs_deg, int nDirs)
+{
+    ensure_device();
+    if (order < 1 || order > SAF_MAX_ORDER || nDirs < 1) SAF_FATAL("sphPWD/sphMUSIC: order 1..7 and at least one grid direction");
+    SphScan* h = new SphScan();
+    h->order = order; h->nSH = ORDER2NSH(order); h->nDirs = nDirs;
+    std::vector<float> rad((size_t)nDirs * 2);
+    for (int i = 0; i < nDirs; i++) { rad[i * 2] = grid_dirs_deg[i * 2] * SAF_PI / 180.0f; rad[i * 2 + 1] = SAF_PI / 2.0f - grid_dirs_deg[i * 2 + 1] * SAF_PI / 180.0f; }
+    h->svecs.resize((size_t)h->nSH * nDirs);
+    getSHreal(order, rad.data(), nDirs, h->svecs.data());
+    h->xyz.resize((size_t)nDirs * 3);
+    for (int i = 0; i < nDirs; i++) {               /* unitSph2cart, degrees */
+        const float az = grid_dirs_deg[i * 2] * SAF_PI / 180.0f, el = grid_dirs_deg[i * 2 + 1] * SAF_PI / 180.0f;
+        h->xyz[i * 3] = cosf(el) * cosf(az); h->xyz[i * 3 + 1] = cosf(el) * sinf(az); h->xyz[i * 3 + 2] = sinf(el);
+    }
+    h->pSpec.resize(nDirs);
+    return h;
+}
+static void sph_scan_peaks(SphScan* h, int nSrcs, int* peak_inds)
+{
+    const float kappa = 50.0f, scale = kappa / (2.0f * SAF_PI * expf(kappa) - expf(-kappa));
+    std::vector<float> P(h->pSpec);
+    for (int k = 0; k < nSrcs; k++) {
+        int pk = 0;
+        for (int i = 1; i < h->nDirs; i++) if (P[i] > P[pk]) pk = i;           /* utility_simaxv: index of the maximum */
+        peak_inds[k] = pk;
+        if (k == nSrcs - 1) break;
+        const float* m = &h->xyz[(size_t)pk * 3];
+        for (int i = 0; i < h->nDirs; i++) {
+            float d = h->xyz[i * 3] * m[0] + h->xyz[i * 3 + 1] * m[1] + h->xyz[i * 3 + 2] * m[2];
+            d = expf(d * kappa) * scale;                                         /* von Mises distribution around the peak */
+            P[i] = P[i] * (1.0f / (0.00001f + d));                               /* ... inverted, as a mask */
+        }
+    }
+}
+void sphPWD_create(void** const phPWD, int order, float* grid_dirs_deg, int nDirs) { *phPWD = sph_scan_create(order, grid_dirs_deg, nDirs); }
+void sphPWD_destroy(void** const phPWD) { delete (SphScan*)*phPWD; *phPWD = nullptr; }
+void sphPWD_compute(void* const hPWD, float_complex* Cx, int nSrcs, float* P_map, int* peak_inds)      /* saf_sh.c:1109-1170 */
+{
+    SphScan* h = (SphScan*)hPWD;
+    std::vector<float2> Y((size_t)h->nSH * h->nDirs);
+    for (size_t i = 0; i < Y.size(); i++) Y[i] = make_float2(h->svecs[i], 0.0f);
+    run_generate_map(1, h->order, Cx, reinterpret_cast<const float_complex*>(Y.data()), h->nDirs, 0.f, 0.f, 0, h->pSpec.data(), nullptr);
+    if (P_map) memcpy(P_map, h->pSpec.data(), sizeof(float) * h->nDirs);
+    if (peak_inds) sph_scan_peaks(h, nSrcs, peak_inds);
+}
+void sphMUSIC_create(void** const phMUSIC, int order, float* grid_dirs_deg, int nDirs) { *phMUSIC = sph_scan_create(order, grid_dirs_deg, nDirs); }
+void sphMUSIC_destroy(void** const phMUSIC) { delete (SphScan*)*phMUSIC; *phMUSIC = nullptr; }
+void sphMUSIC_compute(void* const hMUSIC, float_complex* Vn, int nSrcs, float* P_music, int* peak_inds)   /* saf_sh.c:1243-1306 */
+{
+    SphScan* h = (SphScan*)hMUSIC;
+    const int nSH = h->nSH, G = h->nDirs, VnD2 = nSH - nSrcs;
+    if (nSrcs < 1 || VnD2 < 1) SAF_FATAL("sphMUSIC_compute: 1 <= nSrcs < nSH");
+    /* the noise-subspace basis goes where the sub-space kernel expects it: columns nSrcs .. nSH-1 of a [64][64] matrix */
+    std::vector<float2> V((size_t)64 * 64, make_float2(0.f, 0.f));
+    const float2* vn = reinterpret_cast<const float2*>(Vn);
+    for (int i = 0; i < nSH; i++) for (int j = 0; j < VnD2; j++) V[(size_t)i * 64 + nSrcs + j] = vn[(size_t)i * VnD2 + j];
+    DevBuf<float2> dV, dUn; DevBuf<float> dY, dP, dPrev; DevBuf<int> dSt;
+    dV.alloc(V.size(), false); dUn.alloc(64); dY.alloc(h->svecs.size(), false); dP.alloc(G); dPrev.alloc(G); dSt.alloc(1, false);
+    const int one = 1;
+    HIP_CHECK(hipMemcpyAsync(dV.p, V.data(), sizeof(float2) * V.size(), hipMemcpyHostToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(dY.p, h->svecs.data(), sizeof(float) * h->svecs.size(), hipMemcpyHostToDevice, stream()));
+    HIP_CHECK(hipMemcpyAsync(dSt.p, &one, sizeof(int), hipMemcpyHostToDevice, stream()));
+    AdaptMapLaunch m{};
+    m.Veig = dV.p; m.Un = dUn.p; m.status = dSt.p; m.Ygrid = dY.p; m.pmap = dP.p; m.prev_pmap = dPrev.p;
+    m.nM = nSH; m.G = G; m.mode = 4; m.nSources = nSrcs; m.avg = 0.0f;
+    launch_subspace_map(m);
+    HIP_CHECK(hipMemcpyAsync(h->pSpec.data(), dP.p, sizeof(float) * G, hipMemcpyDeviceToHost, stream()));
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    if (P_music) memcpy(P_music, h->pSpec.data(), sizeof(float) * G);
+    if (peak_inds) sph_scan_peaks(h, nSrcs, peak_inds);
+}
+
 }

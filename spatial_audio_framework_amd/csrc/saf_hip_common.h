@@ -283,5 +283,6 @@ struct AdaptMapLaunch {         /* MVDR / CroPaC-LCMV / MUSIC / MinNorm maps (po
     float2* Wout = nullptr;     /* optional [nM][G] MVDR weights (generateMVDRmap's w_MVDR_out) */
 };
 void launch_adaptive_map(const AdaptMapLaunch& l);
+void launch_subspace_map(const AdaptMapLaunch& l);      /* only the per-direction projection (eigenvectors supplied in Veig) */
 
 }  // namespace saf

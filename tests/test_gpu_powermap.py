@@ -199,3 +199,27 @@ def test_powermap_adaptive_modes_vs_oracle(saf, orc, mode):
                 assert min(np.hypot(az - 50, el - 20), np.hypot(az + 100, el + 30)) < 8.0
             if mode < 6:
                 assert g.getPmap().argmax() == o.getPmap().argmax()
+
+
+def test_reference_sphPWD_and_sphMUSIC_tests_on_gpu(saf, orc):
+    """test__sphPWD (test/src/test__sh_module.c:529-590) and test__sphMUSIC (:454-527) against the GPU objects: order 3,
+    two uncorrelated noise sources on points 139 and 204 of the 240-point t-design, 48000 samples; the peak search must
+    return exactly those two indices (in either order), as the reference asserts.  Maps are also checked in closed form."""
+    order, nSH, lsig = 3, 16, 48000
+    grid = orc.table("Tdesign_degree_21_dirs_deg")
+    src = [139, 204]
+    rng = np.random.default_rng(0)
+    sig = rng.uniform(-1, 1, (2, lsig)).astype(np.float32)                    # rand_m1_1
+    sh = (orc.getRSH(order, grid[src]) @ sig).astype(np.float32)
+    Cx = (sh @ sh.T).astype(np.float32)
+    rad = np.stack([np.radians(grid[:, 0]), np.pi / 2 - np.radians(grid[:, 1])], 1).astype(np.float32)
+    A = orc.getSHreal(order, rad)                                              # steering vectors [nSH][nDirs]
+    P, pk = saf.SphScan("PWD", order, grid).compute(Cx.astype(np.complex64), 2)
+    assert set(pk) == set(src)
+    assert relrms(P, np.einsum("id,ij,jd->d", A.astype(np.float64), Cx.astype(np.float64), A.astype(np.float64))) < 1e-5
+    w, V = np.linalg.eigh(Cx.astype(np.float64))
+    Vn = V[:, ::-1][:, 2:].astype(np.complex64)                               # descending order, noise subspace (utility_sseig + truncation)
+    Pm, pk = saf.SphScan("MUSIC", order, grid).compute(Vn, 2)
+    assert set(pk) == set(src)
+    inv = ((Vn.T.astype(np.complex128) @ A.astype(np.float64)).__abs__() ** 2).sum(0)
+    assert np.abs(1.0 / Pm - inv).max() < 1e-5 * inv.max() + 1e-9
