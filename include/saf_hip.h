@@ -395,6 +395,12 @@ SAF_API int  binauraliser_getProcessingDelay(void);                             
 SAF_API void saf_hip_binauraliser_process_dev(void* const hBin, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
                                               float* d_out, long long out_frame_stride, long long out_ch_stride, int nFrames);
 /** Read-back of the tables binauraliser_data holds (binauraliser_internal.h:95-118), for parity checks. */
+/** Batch of nInst initialised binauralisers (same block size, source count, HRIR set, flags): device-resident blocks
+ *  in[inst*in_inst + frame*in_frame + ch*in_ch + n] -> out[inst*out_inst + frame*out_frame + ear*out_ch + n]; enqueues only. */
+SAF_API void* saf_hip_binauraliser_batch_create(void* const* hBins, int nInst, int maxFramesPerCall);
+SAF_API void  saf_hip_binauraliser_batch_destroy(void** const phBatch);
+SAF_API void  saf_hip_binauraliser_batch_process(void* const hBatch, const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                                 float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride, int nFrames);
 SAF_API void saf_hip_binauraliser_getITDs(void* const hBin, float* itds_s);
 SAF_API void saf_hip_binauraliser_getWeights(void* const hBin, float* weights);
 SAF_API void saf_hip_binauraliser_getHRTFfb(void* const hBin, float_complex* hrtf_fb);        /* [133][2][N] */

@@ -194,6 +194,9 @@ def load():
     sig("binauraliser_getProgressBarText", None, vp, C.c_char_p)
     sig("binauraliser_getSofaFilePath", C.c_char_p, vp)
     sig("saf_hip_binauraliser_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci)
+    sig("saf_hip_binauraliser_batch_create", vp, C.POINTER(vp), ci, ci)
+    sig("saf_hip_binauraliser_batch_destroy", None, C.POINTER(vp))
+    sig("saf_hip_binauraliser_batch_process", None, vp, vp, cll, cll, cll, ci, vp, cll, cll, cll, ci)
     sig("saf_hip_binauraliser_getITDs", None, vp, fp)
     sig("saf_hip_binauraliser_getWeights", None, vp, fp)
     sig("saf_hip_binauraliser_getHRTFfb", None, vp, vp)

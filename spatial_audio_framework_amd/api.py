@@ -532,6 +532,24 @@ class Binauraliser:
             self.L.binauraliser_destroy(C.byref(self.h))
 
 
+class BinauraliserBatch:
+    """saf_hip_binauraliser_batch_*: nInst initialised handles, device-resident blocks."""
+
+    def __init__(self, bins, maxFramesPerCall):
+        self.L = load()
+        self.bins = list(bins)
+        arr = (vp * len(self.bins))(*[b.h for b in self.bins])
+        self.hb = vp(self.L.saf_hip_binauraliser_batch_create(arr, len(self.bins), maxFramesPerCall))
+
+    def process_ptr(self, d_in, in_strides, nIn, d_out, out_strides, nFrames):
+        """strides = (inst, frame, ch) in floats."""
+        self.L.saf_hip_binauraliser_batch_process(self.hb, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nFrames)
+
+    def __del__(self):
+        if getattr(self, "hb", None):
+            self.L.saf_hip_binauraliser_batch_destroy(C.byref(self.hb))
+
+
 # ---------------------------------------------------------------- panner
 class Panner:
     """examples/include/panner.h.  `frameSize` plays the role of -DPANNER_FRAME_SIZE."""

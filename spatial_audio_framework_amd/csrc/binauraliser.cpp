@@ -148,6 +148,27 @@ static void upload_tables(Binauraliser* p)
     p->tablesOnDevice = p->tablesEpoch;
 }
 
+/* rotate source directions (binauraliser.c:230-248) */
+static void rotate_sources(Binauraliser* p)
+{
+    const int nS = p->nSources;
+    if (p->enableRotation && p->recalc_M_rotFLAG) {
+        float R[3][3];
+        rot_matrix(p->yaw, p->pitch, p->roll, p->useRollPitchYawFlag, R);
+        for (int i = 0; i < nS; i++) {
+            const float az = p->src_dirs_deg[i * 2] * SAF_PI / 180.0f, el = p->src_dirs_deg[i * 2 + 1] * SAF_PI / 180.0f;
+            const float x[3] = { cosf(el) * cosf(az), cosf(el) * sinf(az), sinf(el) };
+            float r[3];
+            for (int j = 0; j < 3; j++) { float s = 0; for (int k = 0; k < 3; k++) s += x[k] * R[k][j]; r[j] = s; }
+            const float hyp = sqrtf(powf(r[0], 2.0f) + powf(r[1], 2.0f));
+            p->src_dirs_rot_deg[i * 2] = atan2f(r[1], r[0]) * 180.0f / SAF_PI;
+            p->src_dirs_rot_deg[i * 2 + 1] = atan2f(r[2], hyp) * 180.0f / SAF_PI;
+            p->recalc_hrtf_interpFLAG[i] = 1;
+        }
+        p->recalc_M_rotFLAG = 0;
+    }
+}
+
 /* the block path for nFrames consecutive blocks of device-resident samples */
 static void process_dev(Binauraliser* p, const float* d_in, long long in_frame, long long in_ch, int nIn,
                         float* d_out, long long out_frame, long long out_ch, int nOut, int nFrames)
@@ -181,22 +202,7 @@ static void process_dev(Binauraliser* p, const float* d_in, long long in_frame, 
     launch_analysis(a);
     p->st.anaPar ^= 1;
 
-    /* rotate source directions (binauraliser.c:230-248) */
-    if (p->enableRotation && p->recalc_M_rotFLAG) {
-        float R[3][3];
-        rot_matrix(p->yaw, p->pitch, p->roll, p->useRollPitchYawFlag, R);
-        for (int i = 0; i < nS; i++) {
-            const float az = p->src_dirs_deg[i * 2] * SAF_PI / 180.0f, el = p->src_dirs_deg[i * 2 + 1] * SAF_PI / 180.0f;
-            const float x[3] = { cosf(el) * cosf(az), cosf(el) * sinf(az), sinf(el) };
-            float r[3];
-            for (int j = 0; j < 3; j++) { float s = 0; for (int k = 0; k < 3; k++) s += x[k] * R[k][j]; r[j] = s; }
-            const float hyp = sqrtf(powf(r[0], 2.0f) + powf(r[1], 2.0f));
-            p->src_dirs_rot_deg[i * 2] = atan2f(r[1], r[0]) * 180.0f / SAF_PI;
-            p->src_dirs_rot_deg[i * 2 + 1] = atan2f(r[2], hyp) * 180.0f / SAF_PI;
-            p->recalc_hrtf_interpFLAG[i] = 1;
-        }
-        p->recalc_M_rotFLAG = 0;
-    }
+    rotate_sources(p);
     /* interpolate the HRTFs of the sources that moved (binauraliser.c:252-260) */
     bool any = false;
     for (int ch = 0; ch < nS; ch++) any = any || p->recalc_hrtf_interpFLAG[ch];
@@ -232,6 +238,111 @@ static void process_dev(Binauraliser* p, const float* d_in, long long in_frame, 
     launch_synthesis(s);
     p->st.synPar ^= 1;
 }
+
+/* ---- batch of binauralisers: nInst initialised handles with the same block size, source count, HRIR tables and
+ *      interpolation mode; every call advances all of them by nFrames blocks (own filterbank state, like the ambi_dec batch) ---- */
+struct BinBatch {
+    std::vector<Binauraliser*> inst;
+    int nInst = 0, F = 0, T = 0, maxSrc = 0, nS = 0, maxFrames = 0, Hmax = 0;
+    AfState st;
+    DevBuf<float2> X, Y, hrtfInterp;
+    DevBuf<float> dirs, gains;
+    DevBuf<int> recalc;
+    PinBuf<float> stD, stG; PinBuf<int> stR;
+    std::vector<float> shadowGains;
+
+    void create(Binauraliser* const* h, int n, int maxFrames_)
+    {
+        nInst = n; inst.assign(h, h + n); maxFrames = maxFrames_;
+        Binauraliser* p0 = inst[0];
+        F = p0->F; T = p0->T; maxSrc = p0->maxSrc; nS = p0->nSources;
+        for (int i = 0; i < n; i++) {
+            Binauraliser* p = inst[i];
+            if (p->hrtf_fb.empty() || p->codecStatus != CODEC_STATUS_INITIALISED) SAF_FATAL("binauraliser batch: instance %d is not initialised (call binauraliser_initCodec)", i);
+            if (p->F != F || p->maxSrc != maxSrc || p->nSources != nS) SAF_FATAL("binauraliser batch: all instances must share block size, source cap and source count");
+            if (p->N_hrir_dirs != p0->N_hrir_dirs || p->enableHRIRsDiffuseEQ != p0->enableHRIRsDiffuseEQ || p->fs != p0->fs)
+                SAF_FATAL("binauraliser batch: all instances must share the HRIR set, the diffuse-field EQ flag and the sample rate");
+        }
+        Hmax = (T * maxFrames + 15) & ~15;
+        st.create(nInst, nS, 2);
+        X.alloc((size_t)nInst * SAF_NBANDS * maxSrc * Hmax, true);
+        Y.alloc((size_t)nInst * SAF_NBANDS * 2 * Hmax, true);
+        hrtfInterp.alloc((size_t)nInst * maxSrc * SAF_NBANDS * 2);
+        dirs.alloc((size_t)nInst * maxSrc * 2); gains.alloc((size_t)nInst * maxSrc); recalc.alloc((size_t)nInst * maxSrc);
+        stD.ensure((size_t)nInst * maxSrc * 2 + SAF_NBANDS); stG.ensure((size_t)nInst * maxSrc); stR.ensure((size_t)nInst * maxSrc);
+        for (int i = 0; i < n; i++) for (int ch = 0; ch < maxSrc; ch++) inst[i]->recalc_hrtf_interpFLAG[ch] = 1;      /* a new pipeline starts without interpolated HRTFs */
+    }
+
+    void process(const float* d_in, long long in_inst, long long in_frame, long long in_ch, int nIn,
+                 float* d_out, long long out_inst, long long out_frame, long long out_ch, int nFrames)
+    {
+        if (nFrames <= 0) return;
+        if (nFrames > maxFrames) SAF_FATAL("binauraliser batch: nFrames %d exceeds the maxFramesPerCall %d given at creation", nFrames, maxFrames);
+        Binauraliser* p0 = inst[0];
+        upload_tables(p0);
+        const int H = nFrames * T;
+        /* source gains (binauraliser.c:221-224) */
+        {
+            std::vector<float> g((size_t)nInst * maxSrc);
+            for (int i = 0; i < nInst; i++) for (int ch = 0; ch < maxSrc; ch++) g[(size_t)i * maxSrc + ch] = fabsf(inst[i]->src_gains[ch] - 1.f) > 1e-6f ? inst[i]->src_gains[ch] : 1.0f;
+            if (g != shadowGains) {
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                memcpy(stG.p, g.data(), sizeof(float) * g.size());
+                HIP_CHECK(hipMemcpyAsync(gains.p, stG.p, sizeof(float) * g.size(), hipMemcpyHostToDevice, stream()));
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                shadowGains = g;
+            }
+        }
+        AnaLaunch a{};
+        a.in = d_in; a.in_inst = in_inst; a.in_ch = in_ch; a.in_frame = in_frame; a.hopsPerFrame = T; a.nChIn = nS < nIn ? nS : nIn;
+        a.hist_rd = st.ana[st.anaPar].p; a.hist_wr = st.ana[st.anaPar ^ 1].p;
+        a.out = X.p; a.out_inst = (long long)SAF_NBANDS * maxSrc * Hmax; a.out_band = (long long)maxSrc * Hmax; a.out_ch = Hmax;
+        a.ch_scale = gains.p; a.ch_map = nullptr; a.tab_stride = maxSrc;
+        a.nCh = nS; a.nInst = nInst; a.H = H; a.lowDelay = 0; a.hybrid = 1;
+        launch_analysis(a);
+        st.anaPar ^= 1;
+        /* head rotation and moved sources of every instance (binauraliser.c:230-260) */
+        bool any = false;
+        for (int i = 0; i < nInst; i++) {
+            Binauraliser* p = inst[i];
+            rotate_sources(p);
+            for (int ch = 0; ch < nS; ch++) any = any || p->recalc_hrtf_interpFLAG[ch];
+        }
+        if (any) {
+            HIP_CHECK(hipStreamSynchronize(stream()));
+            for (int i = 0; i < nInst; i++) {
+                Binauraliser* p = inst[i];
+                const std::vector<float>& d = p->enableRotation ? p->src_dirs_rot_deg : p->src_dirs_deg;
+                memcpy(stD.p + (size_t)i * maxSrc * 2, d.data(), sizeof(float) * 2 * maxSrc);
+                for (int ch = 0; ch < maxSrc; ch++) { stR.p[(size_t)i * maxSrc + ch] = ch < nS ? p->recalc_hrtf_interpFLAG[ch] : 0; if (ch < nS) p->recalc_hrtf_interpFLAG[ch] = 0; }
+            }
+            memcpy(stD.p + (size_t)nInst * maxSrc * 2, p0->freqVector, sizeof(float) * SAF_NBANDS);
+            HIP_CHECK(hipMemcpyAsync(dirs.p, stD.p, sizeof(float) * (size_t)nInst * maxSrc * 2, hipMemcpyHostToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(recalc.p, stR.p, sizeof(int) * (size_t)nInst * maxSrc, hipMemcpyHostToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(p0->d_freq.p, stD.p + (size_t)nInst * maxSrc * 2, sizeof(float) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
+            HrtfInterpLaunch l{};
+            l.srcDirs = dirs.p; l.recalc = recalc.p; l.gtComp = p0->d_gtComp.p; l.gtIdx = p0->d_gtIdx.p;
+            l.hrtf_fb = p0->d_hrtf_fb.p; l.hrtf_mag = p0->d_mag.p; l.itds = p0->d_itds.p; l.freq = p0->d_freq.p;
+            l.hrtf_interp = hrtfInterp.p; l.nSrc = nS; l.N = p0->N_hrir_dirs; l.mode = p0->interpMode;
+            l.aziRes = p0->hrtf_vbapTableRes[0]; l.elevRes = p0->hrtf_vbapTableRes[1];
+            l.nInst = nInst; l.srcStride = maxSrc;
+            launch_hrtf_interp(l);
+        }
+        BinMacLaunch m{};
+        m.X = X.p; m.x_inst = a.out_inst; m.x_band = a.out_band; m.x_ch = a.out_ch;
+        m.h = hrtfInterp.p; m.h_inst = (long long)maxSrc * SAF_NBANDS * 2;
+        m.Y = Y.p; m.y_inst = (long long)SAF_NBANDS * 2 * Hmax; m.y_band = (long long)2 * Hmax; m.y_ch = Hmax;
+        m.nSrc = nS; m.H = H; m.scale = 1.0f / sqrtf((float)nS); m.nInst = nInst;
+        launch_binaural_mac(m);
+        SynLaunch s{};
+        s.in = Y.p; s.in_inst = m.y_inst; s.in_band = m.y_band; s.in_ch = m.y_ch;
+        s.out = d_out; s.out_inst = out_inst; s.out_ch = out_ch; s.out_frame = out_frame; s.hopsPerFrame = T;
+        s.hist_rd = st.syn[st.synPar].p; s.hist_wr = st.syn[st.synPar ^ 1].p;
+        s.nCh = 2; s.nInst = nInst; s.H = H; s.lowDelay = 0; s.hybrid = 1;
+        launch_synthesis(s);
+        st.synPar ^= 1;
+    }
+};
 
 }  // namespace saf
 
@@ -445,6 +556,27 @@ void saf_hip_binauraliser_getHRTFinterp(void* const hBin, float_complex* hrtf_in
     PBN;
     HIP_CHECK(hipStreamSynchronize(stream()));
     HIP_CHECK(hipMemcpy((void*)hrtf_interp, p->d_hrtf_interp.p, sizeof(float2) * (size_t)p->nSources * SAF_NBANDS * 2, hipMemcpyDeviceToHost));
+}
+
+void* saf_hip_binauraliser_batch_create(void* const* hBins, int nInst, int maxFramesPerCall)
+{
+    if (nInst < 1 || maxFramesPerCall < 1) SAF_FATAL("binauraliser batch: nInst and maxFramesPerCall must be positive");
+    BinBatch* b = new BinBatch();
+    b->create((Binauraliser* const*)hBins, nInst, maxFramesPerCall);
+    return b;
+}
+void saf_hip_binauraliser_batch_destroy(void** const phBatch)
+{
+    BinBatch* b = (BinBatch*)*phBatch;
+    if (!b) return;
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    delete b;
+    *phBatch = nullptr;
+}
+void saf_hip_binauraliser_batch_process(void* const hBatch, const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                        float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride, int nFrames)
+{
+    ((BinBatch*)hBatch)->process(d_in, in_inst_stride, in_frame_stride, in_ch_stride, nInputs < 0 ? 0 : nInputs, d_out, out_inst_stride, out_frame_stride, out_ch_stride, nFrames);
 }
 
 }

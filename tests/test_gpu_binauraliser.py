@@ -116,3 +116,35 @@ def test_binauraliser_cfg3_256_sources_device_entry(saf, orc, hrirs):
     assert relrms(ya, yo) < TOL
     assert relrms(yb, ya) < 1e-6
     saf.set_stream(None)
+
+
+def test_binauraliser_batch_equals_single_instances(saf, orc, hrirs):
+    """saf_hip_binauraliser_batch_process: 3 instances with different source layouts, gains and head rotations, 2 calls of
+    4 blocks; each instance must equal its own oracle run; a source is moved between the calls."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    F, nS, nI, nF = 256, 24, 3, 4
+    pairs = [setup_pair(saf, orc, hrirs, F, nS, mode=2) for _ in range(nI)]
+    rng = np.random.default_rng(12)
+    for i, (g, o) in enumerate(pairs):
+        for b in (g, o):
+            for s in range(nS):
+                b.setSourceAzi_deg(s, float((37 * s + 90 * i) % 360 - 180)); b.setSourceElev_deg(s, float((11 * s + 20 * i) % 140 - 70))
+            b.setSourceGain(i, 0.3)
+            if i == 1:
+                b.setEnableRotation(1); b.setYaw(40.0); b.setRoll(-15.0)
+    bt = saf.BinauraliserBatch([g for g, _ in pairs], nF)
+    x = np.stack([frames(90 + i, nS, 2 * nF * F) for i in range(nI)])                  # [inst][ch][time]
+    d_in = torch.from_numpy(x).cuda(); d_out = torch.zeros(nI, 2, 2 * nF * F, device="cuda")
+    for call in range(2):
+        if call == 1:
+            for b in pairs[2]:
+                b.setSourceAzi_deg(5, 12.0)
+        off = call * nF * F * 4
+        bt.process_ptr(d_in.data_ptr() + off, (nS * 2 * nF * F, F, 2 * nF * F), nS, d_out.data_ptr() + off, (2 * 2 * nF * F, F, 2 * nF * F), nF)
+        torch.cuda.synchronize()
+        for i, (_, o) in enumerate(pairs):
+            yo = np.concatenate([o.process(np.ascontiguousarray(x[i][:, (call * nF + f) * F:(call * nF + f + 1) * F])) for f in range(nF)], 1)
+            yg = d_out[i][:, call * nF * F:(call + 1) * nF * F].cpu().numpy()
+            assert relrms(yg, yo) < TOL or (call == 0 and np.abs(yo).max() < 1e-3), (call, i)
+    saf.set_stream(None)

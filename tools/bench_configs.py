@@ -244,6 +244,18 @@ def main():
                     "batch": "1 handle x 16 frames per call", "kernels_ms": per,
                     "roofline": {"bound": "latency", "note": "one 64 x 64 factorisation per map in a single workgroup (float64 in LDS)"},
                     "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s (map every frame; float64 Jacobi / Cholesky port)", "cores": 1, "kind": "port"}})
+
+    # ---- configs[2] at throughput: 16 binauralisers x 256 sources in one batch
+    F, nS, nI, nF = 128, 256, 16, 64
+    bins = [mkbin(api.Binauraliser) for _ in range(nI)]
+    bb = api.BinauraliserBatch(bins, nF)
+    x = torch.rand(nI, nS, nF * F, device="cuda") * 2 - 1; y = torch.zeros(nI, 2, nF * F, device="cuda")
+    t, per = timed(L, torch, lambda: bb.process_ptr(x.data_ptr(), (nS * nF * F, F, nF * F), nS, y.data_ptr(), (2 * nF * F, F, nF * F), nF), steps, warm,
+                   ["afstft_analysis", "binaural_mac", "afstft_synthesis"])
+    out.append({"config": "binauraliser batch: 16 handles x 256 virtual sources, 128-sample blocks (configs[2] at throughput)", "value": round(nI * nF / t, 1), "unit": "frames/s",
+                "batch": f"{nI} handles x {nF} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": nS * F * 4 + 2 * F * 4, "path_achieved_GBps": round((nS * F * 4 + 2 * F * 4) * nI * nF / t / 1e9, 1), "peak_GBps": HBM},
+                "cpu_baseline": out[1]["cpu_baseline"]})
     for o in out:
         print(json.dumps(o), flush=True)
 
