@@ -585,6 +585,85 @@ SAF_API void saf_rfft_destroy(void** const phFFT);                              
 SAF_API void saf_rfft_forward(void* const hFFT, float* inputTD, float_complex* outputFD);  /* saf_utility_fft.c:690 */
 SAF_API void saf_rfft_backward(void* const hFFT, float_complex* inputFD, float* outputTD); /* saf_utility_fft.c:728 */
 
+/* ========================================================================== */
+/*      binaural Ambisonic decoding: design functions and the ambi_bin operator  */
+/* ========================================================================== */
+typedef enum {                                                                    /* saf_hoa.h:134-171 */
+    BINAURAL_DECODER_DEFAULT = 0, BINAURAL_DECODER_LS, BINAURAL_DECODER_LSDIFFEQ, BINAURAL_DECODER_SPR, BINAURAL_DECODER_TA, BINAURAL_DECODER_MAGLS
+} BINAURAL_AMBI_DECODER_METHODS;
+typedef enum { SH_ORDER_FIRST = 1, SH_ORDER_SECOND, SH_ORDER_THIRD, SH_ORDER_FOURTH, SH_ORDER_FIFTH, SH_ORDER_SIXTH, SH_ORDER_SEVENTH } SH_ORDERS;   /* _common.h:38-48 */
+typedef enum { DECODING_METHOD_LS = 1, DECODING_METHOD_LSDIFFEQ, DECODING_METHOD_SPR, DECODING_METHOD_TA, DECODING_METHOD_MAGLS } AMBI_BIN_DECODING_METHODS;   /* ambi_bin.h:126-135 */
+typedef enum { HRIR_PREPROC_OFF = 1, HRIR_PREPROC_EQ, HRIR_PREPROC_PHASE, HRIR_PREPROC_ALL } AMBI_BIN_PREPROC;                                               /* ambi_bin.h:141-146 */
+SAF_API void getSHrotMtxReal(float Rxyz[3][3], float* RotMtx, int L);                                                  /* saf_sh.h / saf_sh.c:479 */
+SAF_API void yawPitchRoll2Rzyx(float yaw, float pitch, float roll, int rollPitchYawFLAG, float R[3][3]);               /* saf_utility_geometry.c:213 */
+SAF_API void beamWeightsMaxEV(int N, float* b_n);                                                                      /* saf_sh.c:751 */
+SAF_API void truncationEQ(float* w_n, int order_truncated, int order_target, double* kr, int nBands, float softThreshold, float* gain);   /* saf_hoa.c:269 */
+/** hrtfs: N_bands x 2 x N_dirs; decMtx: N_bands x 2 x (order+1)^2 (saf_hoa.h:394-450).  itd_s is accepted and unused, as in the
+ *  reference (its time-alignment phase term multiplies the ITD by zero, saf_hoa_internal.c:495-498). */
+SAF_API void getBinauralAmbiDecoderMtx(float_complex* hrtfs, float* hrtf_dirs_deg, int N_dirs, int N_bands, BINAURAL_AMBI_DECODER_METHODS method, int order,
+                                       float* freqVector, float* itd_s, float* weights, int enableDiffCovMatching, int enableMaxReWeighting, float_complex* decMtx);
+SAF_API void applyDiffCovMatching(float_complex* hrtfs, float* hrtf_dirs_deg, int N_dirs, int N_bands, int order, float* weights, float_complex* decMtx);   /* saf_hoa.c:502 */
+/** Replaces -DAMBI_BIN_FRAME_SIZE; call before ambi_bin_create. */
+SAF_API void saf_hip_ambi_bin_setFrameSize(int frameSize);
+SAF_API void ambi_bin_create(void** const phAmbi);                                 /* ambi_bin.h:161 */
+SAF_API void ambi_bin_destroy(void** const phAmbi);                                /* ambi_bin.h:168 */
+SAF_API void ambi_bin_init(void* const hAmbi, int samplerate);                     /* ambi_bin.h:178 */
+SAF_API void ambi_bin_initCodec(void* const hAmbi);                                /* ambi_bin.h:196 */
+SAF_API void ambi_bin_process(void* const hAmbi, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples);   /* ambi_bin.h:208 */
+SAF_API void ambi_bin_refreshParams(void* const hAmbi);                            /* ambi_bin.h:224 */
+SAF_API void ambi_bin_setUseDefaultHRIRsflag(void* const hAmbi, int newState);     /* ambi_bin.h:237 */
+SAF_API void ambi_bin_setSofaFilePath(void* const hAmbi, const char* path);        /* ambi_bin.h:250 */
+SAF_API void ambi_bin_setInputOrderPreset(void* const hAmbi, SH_ORDERS newPreset); /* ambi_bin.h:260 */
+SAF_API void ambi_bin_setDecodingMethod(void* const hAmbi, AMBI_BIN_DECODING_METHODS newMethod);   /* ambi_bin.h:266 */
+SAF_API void ambi_bin_setChOrder(void* const hAmbi, int newOrder);                 /* ambi_bin.h:273 */
+SAF_API void ambi_bin_setNormType(void* const hAmbi, int newType);                 /* ambi_bin.h:279 */
+SAF_API void ambi_bin_setEnableMaxRE(void* const hAmbi, int newState);             /* ambi_bin.h:282 */
+SAF_API void ambi_bin_setEnableDiffuseMatching(void* const hAmbi, int newState);   /* ambi_bin.h:285 */
+SAF_API void ambi_bin_setEnableTruncationEQ(void* const hAmbi, int newState);      /* ambi_bin.h:288 */
+SAF_API void ambi_bin_setHRIRsPreProc(void* const hAmbi, AMBI_BIN_PREPROC newType);/* ambi_bin.h:291 */
+SAF_API void ambi_bin_setEnableRotation(void* const hAmbi, int newState);          /* ambi_bin.h:294 */
+SAF_API void ambi_bin_setYaw(void* const hAmbi, float newYaw_deg);                 /* ambi_bin.h:297 */
+SAF_API void ambi_bin_setPitch(void* const hAmbi, float newPitch);                 /* ambi_bin.h:300 */
+SAF_API void ambi_bin_setRoll(void* const hAmbi, float newRoll);                   /* ambi_bin.h:303 */
+SAF_API void ambi_bin_setFlipYaw(void* const hAmbi, int newState);                 /* ambi_bin.h:306 */
+SAF_API void ambi_bin_setFlipPitch(void* const hAmbi, int newState);               /* ambi_bin.h:309 */
+SAF_API void ambi_bin_setFlipRoll(void* const hAmbi, int newState);                /* ambi_bin.h:312 */
+SAF_API void ambi_bin_setRPYflag(void* const hAmbi, int newState);                 /* ambi_bin.h:318 */
+SAF_API int  ambi_bin_getFrameSize(void);                                          /* ambi_bin.h:329 */
+SAF_API CODEC_STATUS ambi_bin_getCodecStatus(void* const hAmbi);                   /* ambi_bin.h:332 */
+SAF_API float ambi_bin_getProgressBar0_1(void* const hAmbi);                       /* ambi_bin.h:335 */
+SAF_API void ambi_bin_getProgressBarText(void* const hAmbi, char* text);           /* ambi_bin.h:343 */
+SAF_API int  ambi_bin_getUseDefaultHRIRsflag(void* const hAmbi);                   /* ambi_bin.h:353 */
+SAF_API int  ambi_bin_getInputOrderPreset(void* const hAmbi);                      /* ambi_bin.h:362 */
+SAF_API AMBI_BIN_DECODING_METHODS ambi_bin_getDecodingMethod(void* const hAmbi);   /* ambi_bin.h:368 */
+SAF_API char* ambi_bin_getSofaFilePath(void* const hAmbi);                         /* ambi_bin.h:378 */
+SAF_API int  ambi_bin_getChOrder(void* const hAmbi);                               /* ambi_bin.h:385 */
+SAF_API int  ambi_bin_getNormType(void* const hAmbi);                              /* ambi_bin.h:392 */
+SAF_API int  ambi_bin_getNumEars(void);                                            /* ambi_bin.h:395 */
+SAF_API int  ambi_bin_getNSHrequired(void* const hAmbi);                           /* ambi_bin.h:401 */
+SAF_API int  ambi_bin_getEnableMaxRE(void* const hAmbi);                           /* ambi_bin.h:407 */
+SAF_API int  ambi_bin_getEnableDiffuseMatching(void* const hAmbi);                 /* ambi_bin.h:413 */
+SAF_API int  ambi_bin_getEnableTruncationEQ(void* const hAmbi);                    /* ambi_bin.h:419 */
+SAF_API AMBI_BIN_PREPROC ambi_bin_getHRIRsPreProc(void* const hAmbi);              /* ambi_bin.h:425 */
+SAF_API int  ambi_bin_getEnableRotation(void* const hAmbi);                        /* ambi_bin.h:431 */
+SAF_API float ambi_bin_getYaw(void* const hAmbi);                                  /* ambi_bin.h:434 */
+SAF_API float ambi_bin_getPitch(void* const hAmbi);                                /* ambi_bin.h:437 */
+SAF_API float ambi_bin_getRoll(void* const hAmbi);                                 /* ambi_bin.h:440 */
+SAF_API int  ambi_bin_getFlipYaw(void* const hAmbi);                               /* ambi_bin.h:446 */
+SAF_API int  ambi_bin_getFlipPitch(void* const hAmbi);                             /* ambi_bin.h:452 */
+SAF_API int  ambi_bin_getFlipRoll(void* const hAmbi);                              /* ambi_bin.h:458 */
+SAF_API int  ambi_bin_getRPYflag(void* const hAmbi);                               /* ambi_bin.h:464 */
+SAF_API int  ambi_bin_getNDirs(void* const hAmbi);                                 /* ambi_bin.h:467 */
+SAF_API int  ambi_bin_getHRIRlength(void* const hAmbi);                            /* ambi_bin.h:470 */
+SAF_API int  ambi_bin_getHRIRsamplerate(void* const hAmbi);                        /* ambi_bin.h:473 */
+SAF_API int  ambi_bin_getDAWsamplerate(void* const hAmbi);                         /* ambi_bin.h:476 */
+SAF_API int  ambi_bin_getProcessingDelay(void);                                    /* ambi_bin.h:482 */
+/** Device-pointer entry: nFrames consecutive blocks, in[frame*in_frame_stride + ch*in_ch_stride + n] -> out[frame*..., ear*..., n]. */
+SAF_API void saf_hip_ambi_bin_process_dev(void* const hAmbi, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                          float* d_out, long long out_frame_stride, long long out_ch_stride, int nFrames);
+/** Read-back for parity checks: the decoding matrix as [133][2][nSH]. */
+SAF_API void saf_hip_ambi_bin_getDecoderMtx(void* const hAmbi, float_complex* M);
+
 #ifdef __cplusplus
 }
 #endif

@@ -541,6 +541,70 @@ def herm_eig(A):
     return e, vr + 1j * vi
 
 
+# ------------------------------------------------------------------ binaural Ambisonic decoders / ambi_bin
+def getSHrotMtxReal(R, order):
+    R = np.ascontiguousarray(R, np.float32).reshape(9)
+    n = (order + 1) ** 2
+    out = np.zeros((n, n), np.float32)
+    lib().orc_getSHrotMtxReal(fptr(R), fptr(out), order)
+    return out
+
+
+def yawPitchRoll2Rzyx(yaw, pitch, roll, rpy=0):
+    R = np.zeros(9, np.float32)
+    lib().orc_yawPitchRoll2Rzyx(C.c_float(yaw), C.c_float(pitch), C.c_float(roll), rpy, fptr(R))
+    return R.reshape(3, 3)
+
+
+def getBinauralAmbiDecoderMtx(hrtfs, dirs_deg, method, order, freqVector=None, itd_s=None, weights=None, diffMatching=0, maxRE=0):
+    H = np.ascontiguousarray(hrtfs, np.complex64); nBands, _, N = H.shape
+    d = np.ascontiguousarray(dirs_deg, np.float32)
+    fv = np.ascontiguousarray(freqVector if freqVector is not None else np.zeros(nBands), np.float32)
+    it = np.ascontiguousarray(itd_s if itd_s is not None else np.zeros(N), np.float32)
+    w = np.ascontiguousarray(weights, np.float32) if weights is not None else None
+    out = np.zeros((nBands, 2, (order + 1) ** 2), np.complex64)
+    lib().orc_getBinauralAmbiDecoderMtx(H.ctypes.data_as(vp), fptr(d), N, nBands, method, order, fptr(fv), fptr(it), fptr(w) if w is not None else None,
+                                        diffMatching, maxRE, out.ctypes.data_as(vp))
+    return out
+
+
+def truncationEQ(w_n, order_truncated, order_target, kr, softThreshold):
+    w = np.ascontiguousarray(w_n, np.float32); k = np.ascontiguousarray(kr, np.float64); g = np.zeros(k.shape[0], np.float32)
+    lib().orc_truncationEQ(fptr(w), order_truncated, order_target, k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], C.c_float(softThreshold), fptr(g))
+    return g
+
+
+class AmbiBin:
+    def __init__(self, frameSize=128):
+        self.h = vp()
+        self.F = frameSize
+        lib().orc_ambi_bin_create(C.byref(self.h), frameSize)
+        lib().orc_ambi_bin_getDecMtx.restype = vp
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_ambi_bin_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def setHRIRs(self, hrirs, dirs_deg, fs):
+        hrirs = np.ascontiguousarray(hrirs, np.float32); d = np.ascontiguousarray(dirs_deg, np.float32)
+        lib().orc_ambi_bin_setHRIRs(self.h, fptr(hrirs), fptr(d), hrirs.shape[0], hrirs.shape[2], fs)
+
+    def process(self, x, nOut=2, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.zeros((nOut, self.F), np.float32)
+        lib().orc_ambi_bin_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, ns)
+        return y
+
+    def decMtx(self, nSH):
+        p = C.cast(lib().orc_ambi_bin_getDecMtx(self.h), C.POINTER(C.c_float))
+        return np.ctypeslib.as_array(p, shape=(133, 2, 64, 2)).copy().view(np.complex64)[..., 0][:, :, :nSH]
+
+    def __del__(self):
+        if self.h:
+            lib().orc_ambi_bin_destroy(C.byref(self.h))
+
+
 # ------------------------------------------------------------------ panner
 class Panner:
     def __init__(self, frameSize=128):

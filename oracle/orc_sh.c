@@ -338,6 +338,16 @@ static void thin_svd(const float* M, int r, int c, double* U, double* s, double*
     }
 }
 
+/* singular values of a general real matrix (utility_ssvd with only `sing` requested), descending */
+void orc_singular_values(const float* M, int r, int c, float* s)
+{
+    const int k = r < c ? r : c;
+    double* U = (double*)malloc(sizeof(double) * (size_t)r * k); double* sv = (double*)malloc(sizeof(double) * k); double* V = (double*)malloc(sizeof(double) * (size_t)c * k);
+    thin_svd(M, r, c, U, sv, V);
+    for (int i = 0; i < k; i++) s[i] = (float)sv[i];
+    free(U); free(sv); free(V);
+}
+
 /* utility_spinv (saf_utility_veclib.c:3466-3560): singular values <= 1e-5 are
  * multiplied in rather than inverted. out [dim2 x dim1]. */
 void orc_pinv(const float* inM, int dim1, int dim2, float* outM)

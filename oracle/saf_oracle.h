@@ -195,6 +195,39 @@ const orc_cpx* orc_powermap_getCx(void* h);          /* [133][64*64], row stride
 const float* orc_powermap_getRawPmap(void* h);       /* [grid_nDirs] after temporal smoothing */
 int  orc_powermap_getGridNDirs(void* h);
 
+/* ---- binaural Ambisonic decoders, SH rotation, ambi_bin (saf_hoa_internal.c:162-623, saf_hoa.c:394-603, saf_sh.c:479-560, examples/src/ambi_bin) ---- */
+void orc_singular_values(const float* M, int r, int c, float* s);
+void orc_getSHrotMtxReal(const float Rxyz[9], float* RotMtx /* (L+1)^2 x (L+1)^2 */, int L);
+void orc_yawPitchRoll2Rzyx(float yaw, float pitch, float roll, int rollPitchYawFLAG, float R[9]);
+void orc_diffuseFieldEqualiseHRTFs_full(int N, const float* itds_s, const float* centreFreq, int nBands, const float* weights, int applyEQ, int applyPhase, orc_cpx* hrtfs);
+/* method: 1 LS, 2 LSDIFFEQ, 3 SPR, 4 TA, 5 MAGLS (BINAURAL_AMBI_DECODER_METHODS, saf_hoa.h:134-171); hrtfs [nBands][2][N]; decMtx [nBands][2][nSH] */
+void orc_getBinauralAmbiDecoderMtx(const orc_cpx* hrtfs, const float* dirs_deg, int N, int nBands, int method, int order, const float* freqVector,
+                                   const float* itd_s, const float* weights, int enableDiffCovMatching, int enableMaxRE, orc_cpx* decMtx);
+void orc_ambi_bin_create(void** ph, int frameSize);
+void orc_ambi_bin_destroy(void** ph);
+void orc_ambi_bin_setHRIRs(void* h, const float* hrirs, const float* dirs_deg, int N, int len, int fs);
+void orc_ambi_bin_init(void* h, int sampleRate);
+void orc_ambi_bin_initCodec(void* h);
+void orc_ambi_bin_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
+void orc_ambi_bin_setInputOrderPreset(void* h, int o);
+void orc_ambi_bin_setDecodingMethod(void* h, int m);
+void orc_ambi_bin_setChOrder(void* h, int v);
+void orc_ambi_bin_setNormType(void* h, int v);
+void orc_ambi_bin_setEnableMaxRE(void* h, int s);
+void orc_ambi_bin_setEnableDiffuseMatching(void* h, int s);
+void orc_ambi_bin_setEnableTruncationEQ(void* h, int s);
+void orc_ambi_bin_setHRIRsPreProc(void* h, int s);
+void orc_truncationEQ(const float* w_n, int order_truncated, int order_target, const double* kr, int nBands, float softThreshold, float* gain);
+void orc_beamWeightsMaxEV(int N, float* b_n);
+void orc_sphj(int N, double X, int* NM, double* SJ, double* DJ);      /* spherical Bessel j_n, j_n' (Zhang & Jin's SPHJ) */
+void orc_sphy(int N, double X, int* NM, double* SY, double* DY);      /* spherical Bessel y_n, y_n' (SPHY) */
+void orc_ambi_bin_setEnableRotation(void* h, int s);
+void orc_ambi_bin_setYaw(void* h, float v);
+void orc_ambi_bin_setPitch(void* h, float v);
+void orc_ambi_bin_setRoll(void* h, float v);
+void orc_ambi_bin_setRPYflag(void* h, int s);
+const orc_cpx* orc_ambi_bin_getDecMtx(void* h);      /* [133][2][64] */
+
 /* ---- matrixconv / multiconv example operators (examples/src/matrixconv, examples/src/multiconv): FIFO around the convolvers ---- */
 void orc_convex_create(void** ph, int matrix /* 1: matrixconv, 0: multiconv */);
 void orc_convex_destroy(void** ph);

@@ -238,6 +238,35 @@ def load():
         for g in ("getEnablePart", "getHostBlockSize", "getNfilters", "getFilterLength", "getFilterFs", "getHostFs", "getProcessingDelay", nin.replace("set", "get")):
             sig(pre + "_" + g, ci, vp)
     sig("matrixconv_getNumOutputChannels", ci, vp)
+    # binaural Ambisonic decoding
+    sig("getSHrotMtxReal", None, fp, fp, ci)
+    sig("yawPitchRoll2Rzyx", None, cf, cf, cf, ci, fp)
+    sig("beamWeightsMaxEV", None, ci, fp)
+    sig("truncationEQ", None, fp, ci, ci, C.POINTER(C.c_double), ci, cf, fp)
+    sig("getBinauralAmbiDecoderMtx", None, vp, fp, ci, ci, ci, ci, fp, fp, fp, ci, ci, vp)
+    sig("applyDiffCovMatching", None, vp, fp, ci, ci, ci, fp, vp)
+    sig("saf_hip_ambi_bin_setFrameSize", None, ci)
+    sig("ambi_bin_create", None, C.POINTER(vp)); sig("ambi_bin_destroy", None, C.POINTER(vp))
+    sig("ambi_bin_init", None, vp, ci); sig("ambi_bin_initCodec", None, vp); sig("ambi_bin_refreshParams", None, vp)
+    sig("ambi_bin_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    for n in ("setUseDefaultHRIRsflag", "setInputOrderPreset", "setDecodingMethod", "setChOrder", "setNormType", "setEnableMaxRE", "setEnableDiffuseMatching",
+              "setEnableTruncationEQ", "setHRIRsPreProc", "setEnableRotation", "setFlipYaw", "setFlipPitch", "setFlipRoll", "setRPYflag"):
+        sig("ambi_bin_" + n, None, vp, ci)
+    for n in ("setYaw", "setPitch", "setRoll"):
+        sig("ambi_bin_" + n, None, vp, cf)
+    sig("ambi_bin_setSofaFilePath", None, vp, C.c_char_p)
+    for n in ("getFrameSize", "getNumEars", "getProcessingDelay"):
+        sig("ambi_bin_" + n, ci)
+    for n in ("getCodecStatus", "getUseDefaultHRIRsflag", "getInputOrderPreset", "getDecodingMethod", "getChOrder", "getNormType", "getNSHrequired", "getEnableMaxRE",
+              "getEnableDiffuseMatching", "getEnableTruncationEQ", "getHRIRsPreProc", "getEnableRotation", "getFlipYaw", "getFlipPitch", "getFlipRoll", "getRPYflag",
+              "getNDirs", "getHRIRlength", "getHRIRsamplerate", "getDAWsamplerate"):
+        sig("ambi_bin_" + n, ci, vp)
+    for n in ("getProgressBar0_1", "getYaw", "getPitch", "getRoll"):
+        sig("ambi_bin_" + n, cf, vp)
+    sig("ambi_bin_getProgressBarText", None, vp, C.c_char_p)
+    sig("ambi_bin_getSofaFilePath", C.c_char_p, vp)
+    sig("saf_hip_ambi_bin_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci)
+    sig("saf_hip_ambi_bin_getDecoderMtx", None, vp, vp)
     # real FFT object
     sig("saf_rfft_create", None, C.POINTER(vp), ci)
     sig("saf_rfft_destroy", None, C.POINTER(vp))

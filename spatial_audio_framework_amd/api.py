@@ -550,6 +550,72 @@ class BinauraliserBatch:
             self.L.saf_hip_binauraliser_batch_destroy(C.byref(self.hb))
 
 
+# ---------------------------------------------------------------- binaural Ambisonic decoding / ambi_bin
+def getSHrotMtxReal(R, order):
+    R = np.ascontiguousarray(R, np.float32).reshape(9); n = (order + 1) ** 2
+    out = np.zeros((n, n), np.float32)
+    load().getSHrotMtxReal(_f(R), _f(out), order); return out
+
+
+def yawPitchRoll2Rzyx(yaw, pitch, roll, rpy=0):
+    R = np.zeros(9, np.float32)
+    load().yawPitchRoll2Rzyx(C.c_float(yaw), C.c_float(pitch), C.c_float(roll), rpy, _f(R)); return R.reshape(3, 3)
+
+
+def getBinauralAmbiDecoderMtx(hrtfs, dirs_deg, method, order, freqVector=None, itd_s=None, weights=None, diffMatching=0, maxRE=0):
+    H = np.ascontiguousarray(hrtfs, np.complex64); nBands, _, N = H.shape
+    d = np.ascontiguousarray(dirs_deg, np.float32)
+    fv = np.ascontiguousarray(freqVector if freqVector is not None else np.zeros(nBands), np.float32)
+    it = np.ascontiguousarray(itd_s if itd_s is not None else np.zeros(N), np.float32)
+    w = np.ascontiguousarray(weights, np.float32) if weights is not None else None
+    out = np.zeros((nBands, 2, (order + 1) ** 2), np.complex64)
+    load().getBinauralAmbiDecoderMtx(H.ctypes.data_as(vp), _f(d), N, nBands, method, order, _f(fv), _f(it), _f(w) if w is not None else None,
+                                     diffMatching, maxRE, out.ctypes.data_as(vp))
+    return out
+
+
+def truncationEQ(w_n, order_truncated, order_target, kr, softThreshold):
+    w = np.ascontiguousarray(w_n, np.float32); k = np.ascontiguousarray(kr, np.float64); g = np.zeros(k.shape[0], np.float32)
+    load().truncationEQ(_f(w), order_truncated, order_target, k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], C.c_float(softThreshold), _f(g)); return g
+
+
+class AmbiBin:
+    """examples/include/ambi_bin.h.  `frameSize` plays the role of -DAMBI_BIN_FRAME_SIZE."""
+
+    def __init__(self, frameSize=128):
+        self.L = load()
+        self.L.saf_hip_ambi_bin_setFrameSize(frameSize)
+        self.h = vp(); self.F = frameSize
+        self.L.ambi_bin_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "ambi_bin_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def setHRIRs(self, hrirs, dirs_deg, fs):
+        setDefaultHRIRs(hrirs, dirs_deg, fs)
+        self.L.ambi_bin_refreshParams(self.h)
+
+    def process(self, x, nOut=2, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.ambi_bin_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def process_dev(self, d_in, in_strides, nIn, d_out, out_strides, nFrames):
+        """strides = (frame, ch) in floats."""
+        self.L.saf_hip_ambi_bin_process_dev(self.h, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nFrames)
+
+    def decMtx(self, nSH):
+        out = np.zeros((133, 2, nSH), np.complex64)
+        self.L.saf_hip_ambi_bin_getDecoderMtx(self.h, out.ctypes.data_as(vp)); return out
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ambi_bin_destroy(C.byref(self.h))
+
+
 # ---------------------------------------------------------------- panner
 class Panner:
     """examples/include/panner.h.  `frameSize` plays the role of -DPANNER_FRAME_SIZE."""

@@ -61,7 +61,22 @@ def generate(O):
     out["conv_small"] = conv_scenarios(O.MultiConv, O.TVConv)
     out["ambi_dec_bin_small"] = {"out": ambi_dec_bin_scenario(O.AmbiDec)}
     out["pmaps_small"] = pmaps_scenario(O)
+    out["ambi_bin_small"] = {"out": ambi_bin_scenario(O.AmbiBin)}
     return out
+
+
+def ambi_bin_scenario(cls, F=128, nB=20):
+    """order 2 -> 2 ears, MagLS + max-rE (the reference's defaults), SN3D input, rotation switched on at block 10"""
+    h, d = synth_hrirs()
+    a = cls(F)
+    a.setHRIRs(h, d, 48000); a.setInputOrderPreset(2); a.init(48000); a.initCodec()
+    x = frames(808, 9, nB * F)
+    ys = []
+    for b in range(nB):
+        if b == 10:
+            a.setEnableRotation(1); a.setYaw(45.0); a.setPitch(10.0)
+        ys.append(a.process(x[:, b * F:(b + 1) * F], 2))
+    return np.concatenate(ys, 1)
 
 
 def panner_scenario(cls, F=128, nB=16):

@@ -34,6 +34,10 @@ def test_golden_ambi_dec_binaural(saf):
     assert relrms(mg.ambi_dec_bin_scenario(saf.AmbiDec), np.load(GOLD / "ambi_dec_bin_small.npz")["out"]) < TOL
 
 
+def test_golden_ambi_bin(saf):
+    assert relrms(mg.ambi_bin_scenario(saf.AmbiBin), np.load(GOLD / "ambi_bin_small.npz")["out"]) < 3e-5      # MagLS phase chain
+
+
 def test_golden_activity_maps(saf, orc):
     ref = np.load(GOLD / "pmaps_small.npz")
     order = 3

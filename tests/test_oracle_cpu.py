@@ -498,3 +498,52 @@ def test_adaptive_map_generators_closed_forms(orc):
     pm, w = orc.generateMVDRmap(order, Cx, Yg, weights=True)
     assert np.abs((w * Yg).sum(0) - 1).max() < 1e-5
     assert np.all(orc.generateMVDRmap(order, np.zeros_like(Cx), Yg) == 0)
+
+
+def test_binaural_ambi_decoders_closed_forms(orc):
+    """getSHrotMtxReal / getBinauralAmbiDecoderMtx / applyDiffCovMatching / truncationEQ have no reference test.  Closed forms:
+    the rotation matrix is orthonormal and maps the SH of directions to the SH of the rotated directions; an order-limited
+    HRTF set is decoded exactly by LS and LSDIFFEQ (gain 1); max-rE scales each order by its weight; after covariance
+    matching the order-limited set has the diffuse-field covariance of the original (the Nyquist band is left alone);
+    the truncation EQ equals the closed form built from scipy's spherical Bessel functions."""
+    from util import synth_hrirs
+    rng = np.random.default_rng(0)
+    order = 4
+    R = orc.yawPitchRoll2Rzyx(0.7, -0.3, 0.2)
+    M = orc.getSHrotMtxReal(R, order)
+    assert np.abs(M @ M.T - np.eye(25)).max() < 2e-6
+    d = np.stack([rng.uniform(-180, 180, 50), rng.uniform(-80, 80, 50)], 1).astype(np.float32)
+    az, el = np.radians(d[:, 0]), np.radians(d[:, 1])
+    xyz = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1) @ R.T
+    d2 = np.stack([np.degrees(np.arctan2(xyz[:, 1], xyz[:, 0])), np.degrees(np.arcsin(np.clip(xyz[:, 2], -1, 1)))], 1).astype(np.float32)
+    assert np.abs(M @ orc.getRSH(order, d) - orc.getRSH(order, d2)).max() < 1e-5
+    _, dd = synth_hrirs()
+    N, order, nSH = dd.shape[0], 3, 16
+    Y = orc.getRSH(order, dd)
+    c = (rng.normal(size=(5, 2, nSH)) + 1j * rng.normal(size=(5, 2, nSH))).astype(np.complex64)
+    H = np.einsum("bei,ik->bek", c, Y).astype(np.complex64)
+    w = orc.getVoronoiWeights(dd)
+    for m in (1, 2):
+        assert np.abs(orc.getBinauralAmbiDecoderMtx(H, dd, m, order, weights=w) - c).max() < 2e-5
+    assert np.abs(orc.getBinauralAmbiDecoderMtx(H, dd, 3, order, weights=w) - c).max() < 0.05          # SPR: quadrature of the t-design
+    Dre = orc.getBinauralAmbiDecoderMtx(H, dd, 1, order, weights=w, maxRE=1)
+    a = np.diag(orc.getMaxREweights(order)) if orc.getMaxREweights(order).ndim == 2 else orc.getMaxREweights(order)
+    assert np.allclose((Dre / c).real, np.broadcast_to(a, c.shape), atol=1e-4)
+    Hg = (rng.normal(size=(5, 2, N)) + 1j * rng.normal(size=(5, 2, N))).astype(np.complex64)
+    D = orc.getBinauralAmbiDecoderMtx(Hg, dd, 1, order, weights=w, diffMatching=1)
+    Ha = np.einsum("bei,ik->bek", D, Y)
+    Cref = np.einsum("bek,k,bfk->bef", Hg, w, Hg.conj()); Camb = np.einsum("bek,k,bfk->bef", Ha, w, Ha.conj())
+    assert np.abs(Cref[:4] - Camb[:4]).max() < 1e-5 * np.abs(Cref).max() and np.abs(Cref[4] - Camb[4]).max() > 0.1 * np.abs(Cref).max()
+    from scipy.special import spherical_jn, spherical_yn
+    # (from 2 kHz up: for small kr the reference's Bessel start-order estimate — natural instead of decimal logarithms in ENVJ,
+    #  saf_utility_bessel.c:40-47 — stops below order 42, and sphModalCoeffs then drops those orders for ALL bands; restated as is)
+    f = np.linspace(2000, 24000, 60); kr = 2 * np.pi / 343.0 * f * 0.085
+
+    def b2(n, x):
+        jn, djn = spherical_jn(n, x), spherical_jn(n, x, True)
+        hn, dhn = jn - 1j * spherical_yn(n, x), djn - 1j * spherical_yn(n, x, True)
+        return np.abs(4 * np.pi * (jn - djn / dhn * hn)) ** 2
+    pt = sum((2 * n + 1) * b2(n, kr) for n in range(43)); pq = sum((2 * n + 1) * b2(n, kr) for n in range(4))
+    g = np.sqrt(pt) / np.sqrt(pq) / 10 ** (9 / 20)
+    g = np.where(g > 1, 1 + np.tanh(g - 1), g) * 10 ** (9 / 20)
+    assert np.abs(orc.truncationEQ(np.ones(4, np.float32), 3, 42, kr, 9.0) - g).max() < 1e-3

@@ -256,6 +256,20 @@ def main():
                 "batch": f"{nI} handles x {nF} blocks per call", "kernels_ms": per,
                 "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": nS * F * 4 + 2 * F * 4, "path_achieved_GBps": round((nS * F * 4 + 2 * F * 4) * nI * nF / t / 1e9, 1), "peak_GBps": HBM},
                 "cpu_baseline": out[1]["cpu_baseline"]})
+
+    # ---- SURVEY 8f-4 (second half): ambi_bin order 7 -> 2 ears (MagLS, max-rE), F = 512, one handle
+    F, nF = 512, 64
+    def mkab(cls):
+        a = cls(F); a.setHRIRs(h, d, 48000); a.setInputOrderPreset(7); a.setNormType(1); a.init(48000); a.initCodec(); return a
+    ga = mkab(api.AmbiBin)
+    x = torch.rand(64, nF * F, device="cuda") * 2 - 1; y = torch.zeros(2, nF * F, device="cuda")
+    t, per = timed(L, torch, lambda: ga.process_dev(x.data_ptr(), (F, nF * F), 64, y.data_ptr(), (F, nF * F), nF), steps, warm, ["afstft_analysis", "binaural_mac", "afstft_synthesis"])
+    oa = mkab(O.AmbiBin); xb = frames(10, 64, F)
+    tc = cpu_time(lambda: oa.process(xb), 6.0)
+    out.append({"config": "ambi_bin (SURVEY 8f-4): order 7 -> 2 ears, MagLS + max-rE, 512-sample blocks, synthetic HRIR set", "value": round(nF / t, 1), "unit": "frames/s",
+                "batch": f"1 handle x {nF} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": 66 * F * 4, "path_achieved_GBps": round(66 * F * 4 * nF / t / 1e9, 1), "peak_GBps": HBM},
+                "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s", "cores": 1, "kind": "port"}})
     for o in out:
         print(json.dumps(o), flush=True)
 
