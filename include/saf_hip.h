@@ -575,6 +575,36 @@ SAF_API int  multiconv_getFilterFs(void* const hMCnv);                          
 SAF_API int  multiconv_getHostFs(void* const hMCnv);                                                                  /* multiconv.h:162 */
 SAF_API int  multiconv_getProcessingDelay(void* const hMCnv);                                                         /* multiconv.h:168 */
 
+SAF_API void tvconv_create(void** const phTVCnv);                                                                     /* tvconv.h:42 */
+SAF_API void tvconv_destroy(void** const phTVCnv);                                                                    /* tvconv.h:49 */
+SAF_API void tvconv_init(void* const hTVCnv, int samplerate, int hostBlockSize);                                      /* tvconv.h:58 */
+SAF_API void tvconv_process(void* const hTVCnv, float** const inputs, float** const outputs, int nInputs, int nOutputs, int nSamples);   /* tvconv.h:72 */
+SAF_API void tvconv_refreshParams(void* const hTVCnv);                                                                /* tvconv.h:88 */
+SAF_API void tvconv_checkReInit(void* const hTVCnv);                                                                  /* tvconv.h:93 */
+SAF_API void tvconv_setFiltersAndPositions(void* const hTVCnv);                                                       /* tvconv.h:96 */
+SAF_API void tvconv_setSofaFilePath(void* const hTVCnv, const char* path);                                            /* tvconv.h:99 */
+SAF_API void tvconv_setTargetPosition(void* const hTVCnv, float position, int dim);                                   /* tvconv.h:108 */
+SAF_API int  tvconv_getNumInputChannels(void* const hTVCnv);                                                          /* tvconv.h:123 */
+SAF_API int  tvconv_getNumOutputChannels(void* const hTVCnv);                                                         /* tvconv.h:129 */
+SAF_API int  tvconv_getHostBlockSize(void* const hTVCnv);                                                             /* tvconv.h:132 */
+SAF_API int  tvconv_getNumIRs(void* const hTVCnv);                                                                    /* tvconv.h:135 */
+SAF_API int  tvconv_getNumListenerPositions(void* const hTVCnv);                                                      /* tvconv.h:138 */
+SAF_API float tvconv_getListenerPosition(void* const hTVCnv, int index, int dim);                                     /* tvconv.h:141 */
+SAF_API int  tvconv_getListenerPositionIdx(void* const hTVCnv);                                                       /* tvconv.h:144 */
+SAF_API float tvconv_getTargetPosition(void* const hTVCnv, int dim);                                                  /* tvconv.h:147 */
+SAF_API float tvconv_getSourcePosition(void* const hTVCnv, int dim);                                                  /* tvconv.h:150 */
+SAF_API float tvconv_getMinDimension(void* const hTVCnv, int dim);                                                    /* tvconv.h:153 */
+SAF_API float tvconv_getMaxDimension(void* const hTVCnv, int dim);                                                    /* tvconv.h:156 */
+SAF_API int  tvconv_getIRLength(void* const hTVCnv);                                                                  /* tvconv.h:159 */
+SAF_API int  tvconv_getIRFs(void* const hTVCnv);                                                                      /* tvconv.h:162 */
+SAF_API int  tvconv_getHostFs(void* const hTVCnv);                                                                    /* tvconv.h:165 */
+SAF_API int  tvconv_getProcessingDelay(void* const hTVCnv);                                                           /* tvconv.h:171 */
+SAF_API char* tvconv_getSofaFilePath(void* const hTVCnv);                                                             /* tvconv.h:174 */
+SAF_API CODEC_STATUS tvconv_getCodecStatus(void* const hTVCnv);                                                       /* tvconv.h */
+/** Installs what the reference reads from a SOFA file (tvconv.c:262-312): irs[nListenerPositions] each FLAT(nIrChannels x irLength),
+ *  listenerPositions [n][3] (Cartesian), sourcePosition [3] (may be NULL). */
+SAF_API void saf_hip_tvconv_setIRsAndPositions(void* const hTVCnv, const float* const* irs, const float* listenerPositions, const float* sourcePosition,
+                                               int nListenerPositions, int nIrChannels, int irLength, int irFs);
 /* ========================================================================== */
 /*      real FFT object (saf_utility_fft.h / saf_utility_fft.c:531-753)        */
 /* ========================================================================== */

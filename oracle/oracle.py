@@ -384,6 +384,37 @@ class ConvExample:
             lib().orc_convex_destroy(C.byref(self.h))
 
 
+class TvConvExample:
+    """tvconv example operator with injected IRs / listener positions"""
+
+    def __init__(self):
+        self.h = vp()
+        lib().orc_tvconvex_create(C.byref(self.h))
+
+    def init(self, fs, hostBlockSize):
+        lib().orc_tvconvex_init(self.h, hostBlockSize)
+
+    def setIRsAndPositions(self, irs, positions, fs=48000):
+        irs = np.ascontiguousarray(irs, np.float32); pos = np.ascontiguousarray(positions, np.float32)
+        lib().orc_tvconvex_setIRsAndPositions(self.h, fptr(irs), fptr(pos), irs.shape[0], irs.shape[1], irs.shape[2])
+
+    def setTargetPosition(self, v, dim):
+        lib().orc_tvconvex_setTargetPosition(self.h, C.c_float(v), dim)
+
+    def getListenerPositionIdx(self):
+        return lib().orc_tvconvex_getListenerPositionIdx(self.h)
+
+    def process(self, x, nOut):
+        x = np.ascontiguousarray(x, np.float32).reshape(1, -1)
+        y = np.zeros((nOut, x.shape[1]), np.float32)
+        lib().orc_tvconvex_process(self.h, _chan_ptrs(x), _chan_ptrs(y), 1, nOut, x.shape[1])
+        return y
+
+    def __del__(self):
+        if self.h:
+            lib().orc_tvconvex_destroy(C.byref(self.h))
+
+
 def binaural_mac(inTF, hrtf, nSrc, scale):
     """inTF [nBands][nSrcStride][T] c64, hrtf [nSrc][nBands][2] c64 -> [nBands][2][T]."""
     inTF = np.ascontiguousarray(inTF, np.complex64)

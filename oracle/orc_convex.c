@@ -114,3 +114,91 @@ void orc_convex_process(void* h, const float* const* inputs, float* const* outpu
         }
     }
 }
+
+/* ---------------------------------------------------------------------------------------------------------------------
+ * tvconv example (examples/src/tvconv/tvconv.c, tvconv_internal.c): FIFO around saf_TVConv; the IR set follows the listener
+ * position nearest to the target.  IRs / positions are injected (the reference reads them from a SOFA file).
+ * ------------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+    int FIFO_idx, hostBlockSize, B, nIr, irLen, nPos, nOut, posIdx, reInit, ready;
+    float* inFIFO; float* outFIFO; float* inTD; float* outTD; float* irs; float* pos;
+    float target[3];
+    void* hTV;
+} orc_tvx;
+void orc_tvconvex_create(void** ph)
+{
+    orc_tvx* p = (orc_tvx*)calloc(1, sizeof(orc_tvx));
+    p->hostBlockSize = -1; p->B = MINF; p->reInit = 1;
+    p->inFIFO = (float*)calloc((size_t)MAXCH * MAXF, sizeof(float)); p->outFIFO = (float*)calloc((size_t)MAXCH * MAXF, sizeof(float));
+    *ph = p;
+}
+void orc_tvconvex_destroy(void** ph)
+{
+    orc_tvx* p = (orc_tvx*)*ph; if (!p) return;
+    if (p->hTV) orc_TVConv_destroy(&p->hTV);
+    free(p->inFIFO); free(p->outFIFO); free(p->inTD); free(p->outTD); free(p->irs); free(p->pos); free(p); *ph = NULL;
+}
+static void tvx_check(orc_tvx* p)          /* tvconv_checkReInit (tvconv.c:196-232) */
+{
+    if (p->reInit == 1 && p->irs) {
+        p->reInit = 2;
+        if (p->hTV) orc_TVConv_destroy(&p->hTV);
+        p->B = clampi(p->hostBlockSize, MINF, MAXF);
+        if (p->irLen > 0) orc_TVConv_create(&p->hTV, p->B, p->irs, p->irLen, p->nPos, p->nOut, p->posIdx);
+        p->inTD = (float*)realloc(p->inTD, sizeof(float) * MAXCH * p->B); p->outTD = (float*)realloc(p->outTD, sizeof(float) * MAXCH * p->B);
+        memset(p->inTD, 0, sizeof(float) * MAXCH * p->B); memset(p->outTD, 0, sizeof(float) * MAXCH * p->B);
+        p->FIFO_idx = 0;
+        memset(p->inFIFO, 0, sizeof(float) * MAXCH * MAXF); memset(p->outFIFO, 0, sizeof(float) * MAXCH * MAXF);
+        p->reInit = 0; p->ready = 1;
+    }
+}
+void orc_tvconvex_init(void* h, int hostBlockSize)
+{
+    orc_tvx* p = (orc_tvx*)h;
+    if (p->hostBlockSize != hostBlockSize) { p->hostBlockSize = hostBlockSize; p->B = clampi(hostBlockSize, MINF, MAXF); p->reInit = 1; p->ready = 0; }
+    tvx_check(p);
+}
+/* irs flat [nPos][nIr][irLen]; positions [nPos][3] (tvconv.c:262-312) */
+void orc_tvconvex_setIRsAndPositions(void* h, const float* irs, const float* positions, int nPos, int nIr, int irLen)
+{
+    orc_tvx* p = (orc_tvx*)h;
+    p->irs = (float*)realloc(p->irs, sizeof(float) * (size_t)nPos * nIr * irLen); memcpy(p->irs, irs, sizeof(float) * (size_t)nPos * nIr * irLen);
+    p->pos = (float*)realloc(p->pos, sizeof(float) * (size_t)nPos * 3); memcpy(p->pos, positions, sizeof(float) * (size_t)nPos * 3);
+    p->nPos = nPos; p->nIr = nIr; p->irLen = irLen; p->nOut = nIr < MAXCH ? nIr : MAXCH;
+    for (int d = 0; d < 3; d++) { float mn = positions[d]; for (int i = 1; i < nPos; i++) if (positions[i * 3 + d] < mn) mn = positions[i * 3 + d]; p->target[d] = mn; }
+    p->posIdx = 0; p->ready = 1; p->reInit = 1;
+}
+void orc_tvconvex_setTargetPosition(void* h, float v, int dim)       /* tvconv.c:333-338, tvconv_internal.c:42-61 */
+{
+    orc_tvx* p = (orc_tvx*)h;
+    p->target[dim] = v;
+    int mi = 0; float md = 0.0f;
+    for (int i = 0; i < p->nPos; i++) {
+        float dist = 0.0f;
+        for (int d = 0; d < 3; d++) dist += (p->target[d] - p->pos[i * 3 + d]) * (p->target[d] - p->pos[i * 3 + d]);
+        if (dist < md || i == 0) { md = dist; mi = i; }
+    }
+    p->posIdx = mi;
+}
+int orc_tvconvex_getListenerPositionIdx(void* h) { return ((orc_tvx*)h)->posIdx; }
+void orc_tvconvex_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples)     /* tvconv.c:119-186 */
+{
+    orc_tvx* p = (orc_tvx*)h;
+    tvx_check(p);
+    const int B = p->B, numOut = p->nOut;
+    for (int s = 0; s < nSamples; s++) {
+        int ch;
+        for (ch = 0; ch < (nInputs < 1 ? nInputs : 1); ch++) p->inFIFO[(size_t)ch * MAXF + p->FIFO_idx] = inputs[ch][s];
+        for (; ch < 1; ch++) p->inFIFO[(size_t)ch * MAXF + p->FIFO_idx] = 0.0f;
+        int lim = nOutputs < numOut ? nOutputs : numOut;
+        for (ch = 0; ch < lim; ch++) outputs[ch][s] = p->outFIFO[(size_t)ch * MAXF + p->FIFO_idx];
+        for (; ch < nOutputs; ch++) outputs[ch][s] = 0.0f;
+        p->FIFO_idx++;
+        if (p->FIFO_idx >= B && p->reInit == 0 && p->ready) {
+            p->FIFO_idx = 0;
+            memcpy(p->inTD, p->inFIFO, sizeof(float) * B);
+            if (p->hTV && p->irLen > 0) orc_TVConv_apply(p->hTV, p->inTD, p->outTD, p->posIdx); else memset(p->outTD, 0, sizeof(float) * MAXCH * B);
+            for (int i = 0; i < numOut; i++) memcpy(&p->outFIFO[(size_t)i * MAXF], &p->outTD[(size_t)i * B], sizeof(float) * B);
+        } else if (p->FIFO_idx >= B) { p->FIFO_idx = 0; memset(p->outFIFO, 0, sizeof(float) * MAXCH * MAXF); }
+    }
+}

@@ -239,6 +239,14 @@ int  orc_convex_getProcessingDelay(void* h);
 int  orc_convex_getFilterLength(void* h);
 void orc_convex_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
 
+void orc_tvconvex_create(void** ph);
+void orc_tvconvex_destroy(void** ph);
+void orc_tvconvex_init(void* h, int hostBlockSize);
+void orc_tvconvex_setIRsAndPositions(void* h, const float* irs /* [nPos][nIr][irLen] */, const float* positions /* [nPos][3] */, int nPos, int nIr, int irLen);
+void orc_tvconvex_setTargetPosition(void* h, float v, int dim);
+int  orc_tvconvex_getListenerPositionIdx(void* h);
+void orc_tvconvex_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
+
 /* ---- adaptive / sub-space activity maps (saf_sh.c:1586-1858); Y_grid is the REAL [nSH][G] matrix (the reference passes it as complex with zero imaginary part) ---- */
 void orc_generateMVDRmap(int order, const orc_cpx* Cx, const float* Y_grid, int G, float regPar, float* pmap, orc_cpx* w_MVDR_out /* [nSH][G] or NULL */);
 void orc_generateCroPaCLCMVmap(int order, const orc_cpx* Cx, const float* Y_grid, int G, float regPar, float lambda, float* pmap);

@@ -272,6 +272,20 @@ def load():
     sig("saf_rfft_destroy", None, C.POINTER(vp))
     sig("saf_rfft_forward", None, vp, fp, vp)
     sig("saf_rfft_backward", None, vp, vp, fp)
+    sig("tvconv_create", None, C.POINTER(vp)); sig("tvconv_destroy", None, C.POINTER(vp))
+    sig("tvconv_init", None, vp, ci, ci)
+    sig("tvconv_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("tvconv_refreshParams", None, vp); sig("tvconv_checkReInit", None, vp); sig("tvconv_setFiltersAndPositions", None, vp)
+    sig("tvconv_setSofaFilePath", None, vp, C.c_char_p)
+    sig("tvconv_setTargetPosition", None, vp, cf, ci)
+    for g in ("getNumInputChannels", "getNumOutputChannels", "getHostBlockSize", "getNumIRs", "getNumListenerPositions", "getListenerPositionIdx", "getIRLength", "getIRFs",
+              "getHostFs", "getProcessingDelay", "getCodecStatus"):
+        sig("tvconv_" + g, ci, vp)
+    for g in ("getTargetPosition", "getSourcePosition", "getMinDimension", "getMaxDimension"):
+        sig("tvconv_" + g, cf, vp, ci)
+    sig("tvconv_getListenerPosition", cf, vp, ci, ci)
+    sig("tvconv_getSofaFilePath", C.c_char_p, vp)
+    sig("saf_hip_tvconv_setIRsAndPositions", None, vp, C.POINTER(fp), fp, fp, ci, ci, ci, ci)
     # activity-map generators
     sig("generatePWDmap", None, ci, vp, vp, ci, fp)
     sig("generateMVDRmap", None, ci, vp, vp, ci, cf, fp, vp)

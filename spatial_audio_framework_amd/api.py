@@ -452,6 +452,34 @@ class Rfft:
             self.L.saf_rfft_destroy(C.byref(self.h))
 
 
+class TvConvExample:
+    """tvconv example operator (examples/include/tvconv.h) with IRs / listener positions installed directly"""
+
+    def __init__(self):
+        self.L = load(); self.h = vp()
+        self.L.tvconv_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "tvconv_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def setIRsAndPositions(self, irs, positions, fs=48000):
+        irs = np.ascontiguousarray(irs, np.float32); pos = np.ascontiguousarray(positions, np.float32)
+        flat = irs.reshape(irs.shape[0], -1)
+        rows = (C.POINTER(C.c_float) * irs.shape[0])(*[_f(flat[i]) for i in range(irs.shape[0])])
+        self.L.saf_hip_tvconv_setIRsAndPositions(self.h, rows, _f(pos), None, irs.shape[0], irs.shape[1], irs.shape[2], fs)
+
+    def process(self, x, nOut):
+        x = np.ascontiguousarray(x, np.float32).reshape(1, -1)
+        y = np.full((nOut, x.shape[1]), np.nan, np.float32)
+        self.L.tvconv_process(self.h, _rows(x), _rows(y), 1, nOut, x.shape[1])
+        return y
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.tvconv_destroy(C.byref(self.h))
+
+
 # ---------------------------------------------------------------- HRIR processing / binauraliser
 def estimateITDs(hrirs, fs):
     hrirs = np.ascontiguousarray(hrirs, np.float32)

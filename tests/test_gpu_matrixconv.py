@@ -179,3 +179,25 @@ def test_conv_example_wrappers_vs_oracle(saf, orc, matrix):
     yg, yo = np.concatenate(yg, 1), np.concatenate(yo, 1)
     assert np.all(yg[nOut] == 0) and np.abs(yo).max() > 0.1
     assert relrms(yg, yo) < TOL
+
+
+def test_tvconv_example_wrapper_vs_oracle(saf, orc):
+    """tvconv example operator: FIFO around saf_TVConv, IR set = listener position nearest to the moving target; IRs and
+    positions installed directly (the reference reads them from a SOFA file)."""
+    rng = np.random.default_rng(21)
+    nPos, nIr, L = 6, 3, 900
+    irs = (rng.normal(size=(nPos, nIr, L)) / 16).astype(np.float32)
+    pos = np.stack([np.linspace(0, 5, nPos), np.zeros(nPos), np.full(nPos, 1.5)], 1).astype(np.float32)
+    g, o = saf.TvConvExample(), orc.TvConvExample()
+    for c in (g, o):
+        c.setIRsAndPositions(irs, pos); c.init(48000, 512)
+    assert g.getNumListenerPositions() == nPos and g.getNumOutputChannels() == nIr and g.getProcessingDelay() == 512
+    x = frames(88, 1, 7000)[0]
+    p0, yg, yo = 0, [], []
+    for k, n in enumerate((300, 724, 512, 1000, 48, 2000, 1024, 1392)):
+        for c in (g, o):
+            c.setTargetPosition(float(0.7 * k), 0)
+        assert g.getListenerPositionIdx() == o.getListenerPositionIdx()
+        yg.append(g.process(x[p0:p0 + n], nIr + 1)); yo.append(o.process(x[p0:p0 + n], nIr + 1)); p0 += n
+    yg, yo = np.concatenate(yg, 1), np.concatenate(yo, 1)
+    assert np.all(yg[nIr] == 0) and np.abs(yo).max() > 0.05 and relrms(yg, yo) < TOL
