@@ -132,8 +132,9 @@ struct EncPipeline {
         e.out = d_out; e.out_inst = out_inst; e.out_frame = out_frame; e.out_ch = out_ch;
         e.prev_rd = prev[par].p; e.prev_wr = prev[par ^ 1].p;
         e.Afrag = Afrag.p; e.gains = d_gains; e.postScale = d_post; e.rowScale = d_rowScale; e.rowMap = d_rowMap;
-        e.nSrc = d_nSrc; e.mix = anyRecalc ? d_mix : nullptr;
+        e.nSrc = d_nSrc; e.order = d_order; e.mix = anyRecalc ? d_mix : nullptr;
         e.F = F; e.nFrames = nFrames; e.nInst = n; e.nOut = nOut < SAF_MAXCH ? nOut : SAF_MAXCH;
+        for (int i = 0; i < n; i++) e.maxSteps = std::max(e.maxSteps, (shadowI[i] + 1) / 2);
         launch_enc_gemm(e);
         par ^= 1;
         if (anyRecalc)      /* prev_Y <- Y for the instances that mixed (ambi_enc.c:162) */

@@ -173,14 +173,12 @@ void launch_pack_A(const float* d_A, float* d_Afrag, int nMat)
 
 struct EncArgs { EncLaunch e; int frameBase; };
 
-/* grid (column tiles of 128 samples, nFrames + 1, nInst); block row nFrames only saves the last
+/* one block of one instance, columns [128 blockIdx.x, +128); block index nFrames only saves the last
  * input frame (after gains) as the next call's "previous frame" (ambi_enc.c:165). */
-template <bool CANMIX>
-__global__ __launch_bounds__(128) void enc_gemm_kernel(EncArgs a)
+template <bool CANMIX, bool SMALL>
+__device__ __forceinline__ void enc_frame(const EncLaunch& e, int frame, int inst)
 {
 #pragma clang fp contract(off)      /* the reference scales / fades in separate BLAS + veclib calls: keep the roundings */
-    const EncLaunch& e = a.e;
-    const int frame = a.frameBase + blockIdx.y, inst = blockIdx.z;
     const int lane = threadIdx.x & 63, rt = threadIdx.x >> 6;
     const int nSrc = e.nSrc[inst];
     const float* gains = e.gains + inst * SAF_MAXCH;
@@ -214,25 +212,43 @@ __global__ __launch_bounds__(128) void enc_gemm_kernel(EncArgs a)
     const float* A = e.Afrag + ((long long)inst * 2 * 2 + rt) * 32 * 64 + lane;          /* Y */
     const float* Ap = A + 2 * 32 * 64;                                                    /* prev_Y */
 
+    /* SMALL (few sources): the output row tables are fetched before the product so that their latency hides under it,
+     * and since rows >= nSH of Y and columns >= nSrc are zero, a row tile without SH rows and the k-steps past the last
+     * source — which only add zeros — are skipped (4 sources at first order need 2 of the 32 steps of one tile). */
+    float rsv[16]; int orv[16];
+    if (SMALL) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = rt * 32 + tile_row(r, lane);
+            rsv[r] = e.rowScale[inst * SAF_MAXCH + row]; orv[r] = e.rowMap[inst * SAF_MAXCH + row];
+        }
+    }
     Tile128 t, tp;
     tile_zero(t);
     if (mix) tile_zero(tp);
-#pragma unroll 8
-    for (int s = 0; s < 32; s++) {
-        const int k = 2 * s + kh;
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < nSrc) {
-            b = load4_bounded(X + (long long)k * xrow + col, nValid);
-            if (!fromState) { const float gq = gains[k]; b.x *= gq; b.y *= gq; b.z *= gq; b.w *= gq; }
-        }
-        tile_step(t, A[s * 64], b);
-        if (mix) tile_step(tp, Ap[s * 64], b);
+#define ENC_STEP(s)                                                                                          \
+    {                                                                                                        \
+        const int k = 2 * (s) + kh;                                                                          \
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);                                                          \
+        if (k < nSrc) {                                                                                      \
+            b = load4_bounded(X + (long long)k * xrow + col, nValid);                                        \
+            if (!fromState) { const float gq = gains[k]; b.x *= gq; b.y *= gq; b.z *= gq; b.w *= gq; }       \
+        }                                                                                                    \
+        tile_step(t, A[(s) * 64], b);                                                                        \
+        if (mix) tile_step(tp, Ap[(s) * 64], b);                                                             \
     }
+    if (SMALL) {
+        const int nSH = (e.order[inst] + 1) * (e.order[inst] + 1);
+        const int nSteps = rt * 32 < nSH ? (nSrc + 1) >> 1 : 0;
+        for (int s = 0; s < nSteps; s++) ENC_STEP(s)
+    } else {
+#pragma unroll 8
+        for (int s = 0; s < 32; s++) ENC_STEP(s)
+    }
+#undef ENC_STEP
 
     if (nValid <= 0) return;
     const float post = e.postScale[inst];
-    const float* rowScale = e.rowScale + inst * SAF_MAXCH;
-    const int* rowMap = e.rowMap + inst * SAF_MAXCH;
     float fin[4], fout[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {                       /* interpolators of ambi_enc_init (ambi_enc.c:76-79) */
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(128) void enc_gemm_kernel(EncArgs a)
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = rt * 32 + tile_row(r, lane);
-        const int orow = rowMap[row];
+        const int orow = SMALL ? orv[r] : e.rowMap[inst * SAF_MAXCH + row];
         if (orow < 0 || orow >= e.nOut) continue;
         float v[4] = { t.c[0][r], t.c[1][r], t.c[2][r], t.c[3][r] };
         if (mix) {
@@ -251,11 +267,102 @@ __global__ __launch_bounds__(128) void enc_gemm_kernel(EncArgs a)
 #pragma unroll
             for (int c = 0; c < 4; c++) v[c] = fin[c] * v[c] + fout[c] * w[c];
         }
-        const float rs = rowScale[row];
+        const float rs = SMALL ? rsv[r] : e.rowScale[inst * SAF_MAXCH + row];
 #pragma unroll
         for (int c = 0; c < 4; c++) { v[c] = v[c] * post; v[c] = v[c] * rs; }
         store4_bounded(O + (long long)orow * e.out_ch, make_float4(v[0], v[1], v[2], v[3]), nValid);
     }
+}
+
+/* grid (column tiles of 128 samples, nFrames + 1 blocks, nInst) */
+template <bool CANMIX, bool SMALL>
+__global__ __launch_bounds__(128) void enc_gemm_kernel(EncArgs a)
+{
+    enc_frame<CANMIX, SMALL>(a.e, a.frameBase + blockIdx.y, blockIdx.z);
+}
+
+/* Blocks that do not cross-fade, full-size scenes: the product is software-pipelined in groups of 4 k-pair steps (the
+ * loads of group g+1 are in flight under the 16 MFMAs of group g).  Every sample load is unconditional — rows beyond
+ * the present sources re-read the last present row and are zeroed by a select, columns beyond F re-read column 0 —
+ * because a load under a branch gets its own wait (the first version of this loop ran load -> wait -> 4 MFMAs 32 times
+ * in a row).  The Y fragments, the per-source gains and the output row tables sit in LDS: their reads do not share the
+ * samples' vmcnt queue.  128 registers = 4 waves per SIMD. */
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_gemm_full_kernel(EncArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float s_A[2 * 32 * 64];
+    __shared__ float s_g[SAF_MAXCH], s_rs[SAF_MAXCH];
+    __shared__ int s_map[SAF_MAXCH];
+    const EncLaunch& e = a.e;
+    const int frame = a.frameBase + blockIdx.y, inst = blockIdx.z;
+    if (frame == e.nFrames) { enc_frame<false, false>(e, frame, inst); return; }      /* the "previous frame" copy */
+    const int tid = threadIdx.x, lane = tid & 63, rt = tid >> 6, kh = lane >> 5;
+    const int nSrc = e.nSrc[inst];
+    const bool fromState = frame == 0;
+    const float* X = fromState ? e.prev_rd + (long long)inst * SAF_MAXCH * e.F
+                               : e.in + (long long)inst * e.in_inst + (long long)(frame - 1) * e.in_frame;
+    const long long xrow = fromState ? e.F : e.in_ch;
+    const int col = blockIdx.x * 128 + 4 * (lane & 31);
+    const bool colOn = col < e.F;
+    const float* Xc = X + (colOn ? col : 0);
+    const long long lastOff = (long long)(nSrc > 0 ? nSrc - 1 : 0) * xrow;
+    if (nSrc <= 0) Xc = e.prev_rd;                      /* nothing to read: any valid address, every value is masked */
+
+    float4 b[2][4];
+    long long off = (long long)kh * xrow;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { b[0][i] = *reinterpret_cast<const float4*>(Xc + (off < lastOff ? off : lastOff)); off += 2 * xrow; }
+    {
+        const float4* Ag = reinterpret_cast<const float4*>(e.Afrag + (long long)inst * 2 * 2 * 32 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<float4*>(s_A)[tid + 128 * i] = Ag[tid + 128 * i];
+        if (tid < SAF_MAXCH) {
+            s_g[tid] = tid < nSrc ? (fromState ? 1.0f : e.gains[inst * SAF_MAXCH + tid]) : 0.0f;
+            s_rs[tid] = e.rowScale[inst * SAF_MAXCH + tid];
+            s_map[tid] = e.rowMap[inst * SAF_MAXCH + tid];
+        }
+    }
+    const float post = e.postScale[inst];
+    __syncthreads();
+
+    Tile128 t;
+    tile_zero(t);
+    const float* Aw = s_A + rt * 32 * 64 + lane;
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        if (g + 1 < 8) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { b[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(Xc + (off < lastOff ? off : lastOff)); off += 2 * xrow; }
+        }
+        __builtin_amdgcn_sched_barrier(0);          /* keep the prefetch ahead of the group's MFMAs (the scheduler sinks it otherwise) */
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int s = 4 * g + i, k = 2 * s + kh;
+            const float gq = s_g[k];
+            const bool on = k < nSrc;
+            float4 v = b[g & 1][i];
+            v.x = on ? v.x * gq : 0.0f; v.y = on ? v.y * gq : 0.0f; v.z = on ? v.z * gq : 0.0f; v.w = on ? v.w * gq : 0.0f;
+            tile_step(t, Aw[s * 64], v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!colOn) return;
+    float* O = e.out + (long long)inst * e.out_inst + (long long)frame * e.out_frame + col;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = rt * 32 + tile_row(r, lane);
+        const int orow = s_map[row];
+        if (orow < 0 || orow >= e.nOut) continue;
+        const float rs = s_rs[row];
+        float4 v = make_float4(t.c[0][r], t.c[1][r], t.c[2][r], t.c[3][r]);
+        v.x = v.x * post; v.x = v.x * rs; v.y = v.y * post; v.y = v.y * rs; v.z = v.z * post; v.z = v.z * rs; v.w = v.w * post; v.w = v.w * rs;
+        *reinterpret_cast<float4*>(O + (long long)orow * e.out_ch) = v;
+    }
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void enc_gemm_small_kernel(EncArgs a)
+{
+    enc_frame<false, true>(a.e, a.frameBase + blockIdx.y, blockIdx.z);
 }
 
 void launch_enc_gemm(const EncLaunch& e)
@@ -271,10 +378,13 @@ void launch_enc_gemm(const EncLaunch& e)
     const int first = e.mix ? 1 : 0;
     if (first) {
         a.frameBase = 0;
-        hipLaunchKernelGGL(enc_gemm_kernel<true>, dim3((e.F + 127) / 128, 1, e.nInst), dim3(128), 0, stream(), a);
+        hipLaunchKernelGGL((enc_gemm_kernel<true, false>), dim3((e.F + 127) / 128, 1, e.nInst), dim3(128), 0, stream(), a);
     }
     a.frameBase = first;
-    hipLaunchKernelGGL(enc_gemm_kernel<false>, dim3((e.F + 127) / 128, e.nFrames + 1 - first, e.nInst), dim3(128), 0, stream(), a);
+    const int nBlk = e.nFrames + 1 - first;
+    const dim3 grid((e.F + 127) / 128, nBlk, e.nInst);
+    if (e.maxSteps > 0 && e.maxSteps <= 8) hipLaunchKernelGGL(enc_gemm_small_kernel, grid, dim3(128), 0, stream(), a);
+    else hipLaunchKernelGGL(enc_gemm_full_kernel, grid, dim3(128), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 

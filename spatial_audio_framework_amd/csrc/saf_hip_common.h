@@ -183,8 +183,10 @@ struct EncLaunch {
     const float* rowScale;                    /* [nInst][64] N3D -> output norm, by ACN row */
     const int* rowMap;                        /* [nInst][64] ACN row -> output channel */
     const int* nSrc;                          /* [nInst] min(nSources, nInputs present) */
+    const int* order;                         /* [nInst] encoding order: rows >= (order+1)^2 of Y are zero */
     const int* mix;                           /* [nInst] 1: frame 0 cross-fades Y with prev_Y; null: nobody mixes */
     int F, nFrames, nInst, nOut;
+    int maxSteps;                             /* max over instances of ceil(nSrc / 2) (0: unknown) */
 };
 void launch_enc_gemm(const EncLaunch& e);
 

@@ -123,3 +123,29 @@ def test_ambi_enc_batch_equals_single_handles_and_feeds_ambi_dec(saf, orc):
     ref = np.stack([od.process(yo[0, f], 64) for f in range(2 * nF)])
     assert relrms(d_ls[0].cpu().numpy(), ref) < 1e-5
     saf.set_stream(None)
+
+
+@pytest.mark.parametrize("F,nS,nIn,order,nOut,norm", [(200, 23, 20, 5, 30, 2), (512, 40, 40, 6, 64, 1), (132, 17, 17, 3, 16, 1), (96, 9, 9, 2, 12, 2)])
+def test_ambi_enc_mid_size_scenes_ragged_blocks(saf, orc, F, nS, nIn, order, nOut, norm):
+    """Scenes between the two kernel variants' home sizes: block sizes that are not multiples of the 128-column tile,
+    fewer fed channels than sources, per-source gains, fewer outputs than SH channels, a source moved mid-stream
+    (cross-fade block) and post-scaling on."""
+    src = orc.table("SphCovering_64_dirs_deg")
+
+    def mkenc(cls):
+        e = cls(F); e.init(48000)
+        e.setOutputOrder(order); e.setNumSources(nS); e.setNormType(norm); e.setEnablePostScaling(1)
+        for s in range(nS):
+            e.setSourceAzi_deg(s, float(src[s, 0])); e.setSourceElev_deg(s, float(src[s, 1]))
+        e.setSourceGain(1, 0.5); e.setSourceGain(nS - 1, 1.7); e.setSourceGain(4, 0.0)
+        return e
+    g, o = mkenc(saf.AmbiEnc), mkenc(orc.AmbiEnc)
+    x = frames(31, nIn, 7 * F)
+    for f in range(7):
+        if f == 4:
+            for e in (g, o):
+                e.setSourceAzi_deg(2, -100.0); e.setSourceElev_deg(nS - 2, 33.0)
+        blk = np.ascontiguousarray(x[:, f * F:(f + 1) * F])
+        yg, yo = g.process(blk, nOut), o.process(blk, nOut)
+        assert maxabs(yg, yo) < 2e-6, f
+    assert np.abs(yo).max() > 0.1
