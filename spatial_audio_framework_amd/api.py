@@ -36,10 +36,9 @@ def _f(a):
 
 
 def _rows(a):
-    arr = (fp * a.shape[0])()
-    for i in range(a.shape[0]):
-        arr[i] = a[i].ctypes.data_as(fp)
-    return arr
+    """channel-pointer table (float**) of a 2-D float32 array with contiguous rows"""
+    base, stride = a.ctypes.data, a.strides[0]
+    return C.cast((C.c_void_p * a.shape[0])(*[base + i * stride for i in range(a.shape[0])]), C.POINTER(fp))
 
 
 def set_stream(ptr):
