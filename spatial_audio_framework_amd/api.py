@@ -109,7 +109,7 @@ class AfSTFT:
         self.L.saf_hip_afSTFT_backward_dev(self.h, vp(d_fd_ptr), fd_band_stride, fd_ch_stride, nHops, vp(d_td_ptr), td_ch_stride)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.afSTFT_destroy(C.byref(self.h))
 
 
@@ -241,7 +241,7 @@ class AmbiDec:
         return self.L.saf_hip_ambi_dec_getDecoderNorm(self.h, dec, order, which)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.ambi_dec_destroy(C.byref(self.h))
 
 
@@ -263,7 +263,7 @@ class AmbiDecBatch:
         self.L.saf_hip_ambi_dec_batch_clear(self.hb)
 
     def __del__(self):
-        if getattr(self, "hb", None):
+        if getattr(self, "hb", None) and C is not None:
             self.L.saf_hip_ambi_dec_batch_destroy(C.byref(self.hb))
 
 
@@ -290,7 +290,7 @@ class AmbiEnc:
         return y[:, :self.F]
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.ambi_enc_destroy(C.byref(self.h))
 
 
@@ -309,7 +309,7 @@ class AmbiEncBatch:
         self.L.saf_hip_ambi_enc_batch_process(self.hb, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nOut, nFrames)
 
     def __del__(self):
-        if getattr(self, "hb", None):
+        if getattr(self, "hb", None) and C is not None:
             self.L.saf_hip_ambi_enc_batch_destroy(C.byref(self.hb))
 
 
@@ -338,7 +338,7 @@ class MatrixConv:
         self.L.saf_hip_matrixConv_apply_dev(self.h, vp(d_in), *in_strides, vp(d_out), *out_strides, nBlocks)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.saf_matrixConv_destroy(C.byref(self.h))
 
 
@@ -366,7 +366,7 @@ class MultiConv:
         self.L.saf_hip_multiConv_apply_dev(self.h, vp(d_in), *in_strides, vp(d_out), *out_strides, nBlocks)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.saf_multiConv_destroy(C.byref(self.h))
 
 
@@ -396,7 +396,7 @@ class TVConv:
         self.L.saf_hip_TVConv_apply_dev(self.h, vp(d_in), in_block_stride, vp(d_out), *out_strides, idx, nBlocks)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.saf_TVConv_destroy(C.byref(self.h))
 
 
@@ -427,7 +427,7 @@ class ConvExample:
         return y
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             getattr(self.L, self.pre + "_destroy")(C.byref(self.h))
 
 
@@ -447,7 +447,7 @@ class Rfft:
         self.L.saf_rfft_backward(self.h, X.ctypes.data_as(vp), _f(x)); return x
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.saf_rfft_destroy(C.byref(self.h))
 
 
@@ -475,7 +475,7 @@ class TvConvExample:
         return y
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.tvconv_destroy(C.byref(self.h))
 
 
@@ -555,7 +555,7 @@ class Binauraliser:
         self.L.saf_hip_binauraliser_getHRTFinterp(self.h, out.ctypes.data_as(vp)); return out
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.binauraliser_destroy(C.byref(self.h))
 
 
@@ -573,7 +573,7 @@ class BinauraliserBatch:
         self.L.saf_hip_binauraliser_batch_process(self.hb, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nFrames)
 
     def __del__(self):
-        if getattr(self, "hb", None):
+        if getattr(self, "hb", None) and C is not None:
             self.L.saf_hip_binauraliser_batch_destroy(C.byref(self.hb))
 
 
@@ -639,7 +639,7 @@ class AmbiBin:
         self.L.saf_hip_ambi_bin_getDecoderMtx(self.h, out.ctypes.data_as(vp)); return out
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.ambi_bin_destroy(C.byref(self.h))
 
 
@@ -674,7 +674,7 @@ class Panner:
         out = np.zeros((133, 64, 64), np.float32); self.L.saf_hip_panner_getGains(self.h, _f(out)); return out
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.panner_destroy(C.byref(self.h))
 
 
@@ -735,7 +735,7 @@ class SphScan:
         return P, list(pk)
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             getattr(self.L, self.kind + "_destroy")(C.byref(self.h))
 
 
@@ -778,5 +778,5 @@ class Powermap:
         return np.ctypeslib.as_array(pm, shape=(n.value,)).copy()
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and C is not None:
             self.L.powermap_destroy(C.byref(self.h))

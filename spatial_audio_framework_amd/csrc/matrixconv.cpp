@@ -47,16 +47,16 @@ struct MatrixConv {
         else      { nFB = 1; partLen = len; }
         const int Lz = hop + partLen - 1;                                            /* length of one block's linear convolution */
         nOB = (Lz + hop - 1) / hop;                                                  /* = numOvrlpAddBlocks (:71) / 2 in partitioned mode */
-        N = 4; while (N < Lz || N < 2 * hop) N <<= 1;
-        if (N > 32768) SAF_FATAL("matrixConv: transform size %d exceeds the supported 32768 (use the partitioned mode)", N);
-        nBinsP = N / 2 + 4;                                                          /* rows padded to a 16-byte multiple */
+        N = 16; while (N < Lz || N < 2 * hop) N <<= 1;
+        if (N > 16384) SAF_FATAL("matrixConv: transform size %d exceeds the supported 16384 (use the partitioned mode)", N);
+        nBinsP = N / 2;                                                              /* bin 0 carries (Re X[0], Re X[N/2]) */
         xRing = nFB - 1 + maxBlocks; zRing = nOB - 1 + maxBlocks;
         const int nTerms = nFB * nIn;
         /* enough workgroups to pull the filter spectra at HBM rate: split the (partition, input) sum */
-        const int tiles = ((N / 2 + 1 + 63) / 64) * nOut;
-        kSplit = (1024 + tiles - 1) / tiles; if (kSplit > (nTerms + 3) / 4) kSplit = (nTerms + 3) / 4; if (kSplit < 1) kSplit = 1;
+        /* upper bound of the split of the (partition, input) sum; the launcher picks the split per call (pconv_launch_apply) */
+        const int tiles = ((N / 2 + 15) / 16) * ((nOut + 1) / 2);
+        kSplit = (1024 + tiles - 1) / tiles; if (kSplit > (nTerms + 15) / 16) kSplit = (nTerms + 15) / 16; if (kSplit < 1) kSplit = 1;
         termsPerSplit = (nTerms + kSplit - 1) / kSplit;
-        kSplit = (nTerms + termsPerSplit - 1) / termsPerSplit;
         pconv_twiddles(N, tw);
         Hf.alloc((size_t)nOut * nTerms * nBinsP);
         Xr.alloc((size_t)xRing * (diag ? nOut : nIn) * nBinsP);
@@ -110,9 +110,9 @@ struct TVConv {
         if (hop < 2 || len < 1 || nIRs < 1 || nOut < 1) SAF_FATAL("TVConv: bad dimensions");
         posIdx_last = posIdx_last2 = initIdx < nIRs ? initIdx : 0;                  /* saf_utility_matrixConv.c:456-462 */
         nFB = (len + hop - 1) / hop;                                                 /* :468 */
-        N = 4; while (N < 2 * hop) N <<= 1;
-        if (N > 32768) SAF_FATAL("TVConv: transform size %d exceeds the supported 32768", N);
-        nBinsP = N / 2 + 4;
+        N = 16; while (N < 2 * hop) N <<= 1;
+        if (N > 16384) SAF_FATAL("TVConv: transform size %d exceeds the supported 16384", N);
+        nBinsP = N / 2;
         xRing = nFB - 1 + maxBlocks; zRing = 1 + maxBlocks;
         pconv_twiddles(N, tw);
         Hf.alloc((size_t)nIRs * nOut * nFB * nBinsP);
