@@ -1,9 +1,15 @@
 """One process per GPU: how the independent units of the path (decoder / encoder instances, scenes, HRTF sets) are
 sharded over ranks and how per-rank measurements are combined.
 
-The path has no exchange step: every instance owns its state, so ranks never communicate on the data
-path.  `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU tests) is used only for
-the timing barriers, the MAX of the elapsed time and the gathering of results / checksums.
+Independent instances have no exchange step: every instance owns its state, so ranks never communicate on
+the data path.  `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in the CPU tests) is used
+for the timing barriers, the MAX of the elapsed time and the gathering of results / checksums.
+
+The one real exchange the path has is the single-scene case: when ONE sound field is fed by more sources
+than an instance takes (64) and the sources are sharded over ranks, every stage is linear, so each rank renders its
+sources and the ranks' loudspeaker (or SH) blocks are summed: `sum_partial_fields` = one reduce of [channels x samples]
+fp32 per call (128 KiB per 512-sample block of 64 channels; xGMI is point-to-point, so blocks are summed per call of
+many blocks, not per block).
 """
 import os
 
@@ -53,6 +59,19 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def sum_partial_fields(t, root=None):
+    """In-place sum over ranks of the partial sound fields `t` (a tensor on this rank's device: [.., channels, samples]).
+    root = None: every rank receives the sum (all-reduce); root = r: only rank r does (reduce — half the traffic; the
+    other ranks' buffers are left undefined).  Single process: no-op."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    if root is None or (t.is_cuda and dist.get_backend() == "gloo"):      # gloo has no device-tensor reduce
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    else:
+        dist.reduce(t, dst=root, op=dist.ReduceOp.SUM)
+    return t
 
 
 def gather_arrays(local, device="cpu"):

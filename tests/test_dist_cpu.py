@@ -79,6 +79,67 @@ def test_two_rank_gloo_sharding_matches_single_process():
     assert gathered.shape == ref.shape and np.array_equal(gathered, ref)     # no cross-talk, rank order preserved
 
 
+def render_partial_field(O, sources, nFrames=18, F=128, order=2):
+    """The loudspeaker feeds that the given subset of a 12-source scene contributes: ambi_enc (its sources only, no
+    post-scaling) -> ambi_dec.  Linear in the sources."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    from util import frames
+    nSH = (order + 1) ** 2
+    x_all = frames(555, 12, nFrames * F)
+    e = O.AmbiEnc(F); e.init(48000); e.setOutputOrder(order); e.setNumSources(len(sources)); e.setNormType(1); e.setEnablePostScaling(0)
+    for j, s in enumerate(sources):
+        e.setSourceAzi_deg(j, float((53 * s) % 360 - 180)); e.setSourceElev_deg(j, float((29 * s) % 120 - 60))
+    d = O.AmbiDec(F); d.setNormType(1); d.setMasterDecOrder(order); d.setOutputConfigPreset(20)
+    d.setDecMethod(0, 1); d.setDecMethod(1, 1); d.initCodec(); d.init(48000); d.setDecOrderAllBands(order)
+    nLS = d.getNumLoudspeakers()
+    out = []
+    for f in range(nFrames):
+        sh = e.process(np.ascontiguousarray(x_all[list(sources), f * F:(f + 1) * F]), nSH)
+        out.append(d.process(sh, nLS))
+    return np.concatenate(out, 1)
+
+
+def _scene_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import torch
+    from spatial_audio_framework_amd import parallel as P
+    from oracle import oracle as O
+    P.init(backend="gloo")
+    mine = list(P.shard(12, world, rank))
+    part = torch.from_numpy(render_partial_field(O, mine))
+    both = part.clone()
+    P.sum_partial_fields(both)                               # all ranks get the field
+    P.sum_partial_fields(part, root=0)                       # only rank 0 does
+    q.put((rank, both.numpy(), part.numpy() if rank == 0 else None))
+    P.finalize()
+
+
+def test_single_scene_sources_sharded_over_two_ranks():
+    """One sound field, its 12 sources split over 2 ranks: the reduce of the ranks' loudspeaker feeds equals the feeds
+    of the whole scene rendered in one process (every stage is linear) — SURVEY §8e-ii."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scene_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, str(ROOT))
+    from oracle import oracle as O
+    ref = render_partial_field(O, list(range(12)))
+    scale = np.abs(ref).max()
+    assert scale > 0.05
+    for rank, both, rooted in got:
+        assert np.abs(both - ref).max() < 2e-6 * max(1.0, scale)
+        if rank == 0:
+            assert np.abs(rooted - ref).max() < 2e-6 * max(1.0, scale)
+
+
 def test_shard_partition_properties():
     sys.path.insert(0, str(ROOT))
     from spatial_audio_framework_amd.parallel import shard
