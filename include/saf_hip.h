@@ -551,6 +551,7 @@ SAF_API void matrixconv_setNumInputChannels(void* const hMCnv, int newValue);   
 SAF_API int  matrixconv_getEnablePart(void* const hMCnv);                                                             /* matrixconv.h:158 */
 SAF_API int  matrixconv_getNumInputChannels(void* const hMCnv);                                                       /* matrixconv.h:161 */
 SAF_API int  matrixconv_getNumOutputChannels(void* const hMCnv);                                                      /* matrixconv.h:167 */
+SAF_API int  matrixconv_getFrameSize(void);     /* matrixconv.h:152 — declared there, defined nowhere in the reference; here: the smallest internal block (MIN_FRAME_SIZE, 512) */
 SAF_API int  matrixconv_getHostBlockSize(void* const hMCnv);                                                          /* matrixconv.h:170 */
 SAF_API int  matrixconv_getNfilters(void* const hMCnv);                                                               /* matrixconv.h:176 */
 SAF_API int  matrixconv_getFilterLength(void* const hMCnv);                                                           /* matrixconv.h:179 */
@@ -568,6 +569,7 @@ SAF_API void multiconv_setEnablePart(void* const hMCnv, int newState);          
 SAF_API void multiconv_setNumChannels(void* const hMCnv, int newValue);                                               /* multiconv.h:127 */
 SAF_API int  multiconv_getEnablePart(void* const hMCnv);                                                              /* multiconv.h:144 */
 SAF_API int  multiconv_getNumChannels(void* const hMCnv);                                                             /* multiconv.h:147 */
+SAF_API int  multiconv_getFrameSize(void);      /* multiconv.h:138 — as above */
 SAF_API int  multiconv_getHostBlockSize(void* const hMCnv);                                                           /* multiconv.h:150 */
 SAF_API int  multiconv_getNfilters(void* const hMCnv);                                                                /* multiconv.h:153 */
 SAF_API int  multiconv_getFilterLength(void* const hMCnv);                                                            /* multiconv.h:156 */
@@ -586,6 +588,7 @@ SAF_API void tvconv_setSofaFilePath(void* const hTVCnv, const char* path);      
 SAF_API void tvconv_setTargetPosition(void* const hTVCnv, float position, int dim);                                   /* tvconv.h:108 */
 SAF_API int  tvconv_getNumInputChannels(void* const hTVCnv);                                                          /* tvconv.h:123 */
 SAF_API int  tvconv_getNumOutputChannels(void* const hTVCnv);                                                         /* tvconv.h:129 */
+SAF_API int  tvconv_getFrameSize(void);         /* tvconv.h:119 — as above */
 SAF_API int  tvconv_getHostBlockSize(void* const hTVCnv);                                                             /* tvconv.h:132 */
 SAF_API int  tvconv_getNumIRs(void* const hTVCnv);                                                                    /* tvconv.h:135 */
 SAF_API int  tvconv_getNumListenerPositions(void* const hTVCnv);                                                      /* tvconv.h:138 */

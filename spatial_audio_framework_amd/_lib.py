@@ -272,6 +272,8 @@ def load():
     sig("saf_rfft_destroy", None, C.POINTER(vp))
     sig("saf_rfft_forward", None, vp, fp, vp)
     sig("saf_rfft_backward", None, vp, vp, fp)
+    for m in ("matrixconv", "multiconv", "tvconv"):
+        sig(m + "_getFrameSize", ci)
     sig("tvconv_create", None, C.POINTER(vp)); sig("tvconv_destroy", None, C.POINTER(vp))
     sig("tvconv_init", None, vp, ci, ci)
     sig("tvconv_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)

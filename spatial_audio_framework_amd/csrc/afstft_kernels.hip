@@ -340,6 +340,7 @@ struct SynArgs {
     const float* win;
     const float2* twJ;
     const float2* tw256;
+    int chunk;             /* hops per workgroup along time (a multiple of SUB, or H) */
 };
 
 /* Wave-specialised synthesis: one output channel per workgroup of 4 waves.
@@ -349,7 +350,10 @@ struct SynArgs {
  *                         frame history in registers, output stores.
  * The two roles need different registers (gather staging + FFT temporaries vs. the overlap-add window), so the kernel's
  * register count is the larger of the two instead of their sum, and they overlap in time: while the producer's loads are
- * in flight and its FFT runs, the consumer streams the previous sub-chunk out.  Two workgroup barriers per sub-chunk. */
+ * in flight and its FFT runs, the consumer streams the previous sub-chunk out.  Two workgroup barriers per sub-chunk.
+ * grid (channel, instance, time chunk): a chunk that does not start the launch re-synthesises the 16 hops before it to
+ * rebuild the 9-frame overlap-add history (nothing is emitted for them); only used when few (instance, channel)
+ * workgroups exist. */
 __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
 {
     __shared__ __attribute__((aligned(16))) float s_buf[2][SUB * SLOT];
@@ -358,8 +362,11 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
 
     const int tid = threadIdx.x;
     const int ch = blockIdx.x, inst = blockIdx.y;
-    const int H = g.s.H;
-    const int nSub = (H + SUB - 1) / SUB;
+    const int c0 = blockIdx.z * g.chunk;
+    const int H = min(c0 + g.chunk, g.s.H);                      /* end of this workgroup's hops */
+    if (c0 >= H) return;
+    const int hs = c0 > 0 ? c0 - SUB : 0;                        /* first hop synthesised (warm-up sub-chunk before c0) */
+    const int nSub = (H - hs + SUB - 1) / SUB;
     const bool producer = tid < 128;
     for (int k = tid; k < 129; k += 256) s_tw256[k] = g.tw256[k];
     if (tid < 128) s_twJ[tid] = g.twJ[tid];
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
         const unsigned ib32 = (unsigned)g.s.in_band;
         const int gt = tid & 15, gq = tid >> 4;                   /* gather role: hop of the sub-chunk, item lane (8) */
         for (int it = -1; it <= nSub; it++) {
-            const int s0 = it * SUB;
+            const int s0 = hs + it * SUB;
             if (it >= 0 && it < nSub) {
                 /* gather bands -> bins (afHybridInverse, afSTFT_internal.c:625-653): time-contiguous reads, unconditional
                  * loads, all issued before the first use; item = bin pair (k, 128-k), k = gq + 8 i.  The load latency is
@@ -433,18 +440,19 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
         {
             const float* h = g.s.hist_rd + ((long long)inst * g.s.nCh + ch) * SAF_SYN_HIST * 256;
 #pragma unroll
-            for (int i = 0; i < 9; i++) { gl[i] = h[i * 256 + on]; gr[i] = h[i * 256 + 128 + on]; }
+            for (int i = 0; i < 9; i++) { const float a = h[i * 256 + on], b = h[i * 256 + 128 + on]; gl[i] = c0 > 0 ? 0.0f : a; gr[i] = c0 > 0 ? 0.0f : b; }
 #pragma unroll
             for (int i = 9; i < OLA + 9; i++) gl[i] = gr[i] = 0.0f;
         }
         float* outBase = g.s.out + (long long)inst * g.s.out_inst + (long long)ch * g.s.out_ch + on;
-        int oFrame = 0, oSub = 0;                                /* output cursor (uniform): hop -> (frame, hop within the frame) */
+        int oFrame = c0 / T, oSub = c0 - oFrame * T;             /* output cursor (uniform): hop -> (frame, hop within the frame) */
         const float sc = 1.0f / 256.0f;
         /* 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0+t is
          * sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n]; one pass of OLA = 8 hops per barrier interval */
         for (int it = -1; it <= nSub; it++) {
-            const int sp = (it - 1) * SUB;                       /* sub-chunk being emitted */
+            const int sp = hs + (it - 1) * SUB;                  /* sub-chunk being emitted */
             const int np = it >= 1 ? min(SUB, H - sp) : 0;
+            const bool emit = sp >= c0;                          /* the warm-up sub-chunk only rebuilds the frame history */
             const float* ring = s_buf[(it + 1) & 1];
 #pragma unroll
             for (int half = 0; half < SUB / OLA; half++) {       /* one pass of OLA = 8 hops per barrier interval */
@@ -459,8 +467,10 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
                             float acc = 0.0f;
 #pragma unroll
                             for (int k = 9; k >= 0; k--) acc = fmaf(wn[k], (k & 1) ? gr[9 + u - k] : gl[9 + u - k], acc);
-                            outBase[(long long)oFrame * g.s.out_frame + oSub * SAF_HOP] = acc;
-                            oSub++; if (oSub == T) { oSub = 0; oFrame++; }
+                            if (emit) {
+                                outBase[(long long)oFrame * g.s.out_frame + oSub * SAF_HOP] = acc;
+                                oSub++; if (oSub == T) { oSub = 0; oFrame++; }
+                            }
                         }
                     }
                     if (nh == OLA) {
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
                 lds_barrier();                                   /* (A) after the first pass, (B) after the second */
             }
         }
-        if (g.s.hist_wr) {
+        if (g.s.hist_wr && H == g.s.H) {
             float* h = g.s.hist_wr + ((long long)inst * g.s.nCh + ch) * SAF_SYN_HIST * 256;
 #pragma unroll
             for (int i = 0; i < 9; i++) { h[i * 256 + on] = gl[i]; h[i * 256 + 128 + on] = gr[i]; }
@@ -678,7 +688,16 @@ void launch_synthesis(const SynLaunch& s)
     g.win = dev_window(s.lowDelay, 1);
     g.twJ = dev_twiddles();
     g.tw256 = g.twJ + 128;
-    dim3 grid(s.nCh, s.nInst);
+    /* time chunks only when the (instance, channel) grid leaves most of the chip idle: every extra chunk re-synthesises
+     * 16 hops.  Aim at >= 512 workgroups with chunks of >= 64 hops (multiples of 16). */
+    g.chunk = s.H;
+    const long long wgs = (long long)s.nCh * s.nInst;
+    if (wgs < 512 && s.H >= 128) {
+        int nChunks = (int)((512 + wgs - 1) / wgs);
+        if (nChunks > s.H / 64) nChunks = s.H / 64;
+        if (nChunks > 1) g.chunk = ((s.H + nChunks - 1) / nChunks + SUB - 1) / SUB * SUB;
+    }
+    dim3 grid(s.nCh, s.nInst, (s.H + g.chunk - 1) / g.chunk);
     KernelTimer kt("afstft_synthesis");
     hipLaunchKernelGGL(afstft_synthesis_ws_kernel, grid, dim3(256), 0, stream(), g);
     HIP_CHECK(hipGetLastError());

@@ -149,6 +149,7 @@ void matrixconv_setNumInputChannels(void* const hMCnv, int newValue)
 int matrixconv_getEnablePart(void* const hMCnv) { CXP; return p->enablePartitionedConv; }
 int matrixconv_getNumInputChannels(void* const hMCnv) { CXP; return p->nInputChannels; }
 int matrixconv_getNumOutputChannels(void* const hMCnv) { CXP; return p->nOutputChannels; }
+int matrixconv_getFrameSize(void) { return CX_MIN_FRAME; }
 int matrixconv_getHostBlockSize(void* const hMCnv) { CXP; return p->hostBlockSize; }
 int matrixconv_getNfilters(void* const hMCnv) { CXP; return p->nfilters; }
 int matrixconv_getFilterLength(void* const hMCnv) { CXP; return p->filter_length; }
@@ -177,6 +178,7 @@ void multiconv_setEnablePart(void* const hMCnv, int newState) { matrixconv_setEn
 void multiconv_setNumChannels(void* const hMCnv, int newValue) { CXP; p->nInputChannels = clampi(newValue, 1, SAF_MAXCH); }
 int multiconv_getEnablePart(void* const hMCnv) { CXP; return p->enablePartitionedConv; }
 int multiconv_getNumChannels(void* const hMCnv) { CXP; return p->nInputChannels; }
+int multiconv_getFrameSize(void) { return CX_MIN_FRAME; }
 int multiconv_getHostBlockSize(void* const hMCnv) { CXP; return p->hostBlockSize; }
 int multiconv_getNfilters(void* const hMCnv) { CXP; return p->nfilters; }
 int multiconv_getFilterLength(void* const hMCnv) { CXP; return p->filter_length; }
@@ -326,6 +328,7 @@ void tvconv_setTargetPosition(void* const hTVCnv, float position, int dim)
 }
 int tvconv_getNumInputChannels(void* const hTVCnv) { TVP; return p->nInputChannels; }
 int tvconv_getNumOutputChannels(void* const hTVCnv) { TVP; return p->nOutputChannels; }
+int tvconv_getFrameSize(void) { return CX_MIN_FRAME; }
 int tvconv_getHostBlockSize(void* const hTVCnv) { TVP; return p->hostBlockSize; }
 int tvconv_getNumIRs(void* const hTVCnv) { TVP; return p->nIrChannels; }
 int tvconv_getNumListenerPositions(void* const hTVCnv) { TVP; return p->codecStatus == CODEC_STATUS_INITIALISED ? p->nListenerPositions : 0; }

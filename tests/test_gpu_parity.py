@@ -456,3 +456,19 @@ def test_saf_rfft_reference_test_on_gpu(saf, orc, N):
         assert np.abs(X - o.forward(x)).max() <= 3e-6 * np.abs(ref).max()
         Xr = (np.random.default_rng(N).normal(size=N // 2 + 1) + 1j * np.random.default_rng(N + 1).normal(size=N // 2 + 1)).astype(np.complex64)
         assert maxabs(f.backward(Xr), o.backward(Xr)) <= 1e-5      # includes non-zero Im at DC / Nyquist: ignored by both
+
+
+def test_afSTFT_synthesis_time_chunks_bit_identical(saf, orc):
+    """Few channels x many hops: the synthesis grid is split along time (every chunk re-synthesises 16 hops to rebuild its
+    overlap-add history).  One 300-hop call (chunked) == 100 + 37 + 163 hops (the first two unchunked) bit for bit, and
+    both match the oracle; the state after the chunked call continues correctly."""
+    x = frames(15, 3, 340 * 128)
+    a, b, o = saf.AfSTFT(3, 3), saf.AfSTFT(3, 3), orc.AfSTFT(3, 3)
+    A = a.forward(x)
+    Ao = o.forward(x)
+    assert relrms(A, Ao) < 1e-6
+    ya = np.concatenate([a.backward(np.ascontiguousarray(A[:, :, :300])), a.backward(np.ascontiguousarray(A[:, :, 300:]))], axis=1)
+    yb = np.concatenate([b.backward(np.ascontiguousarray(A[:, :, :100])), b.backward(np.ascontiguousarray(A[:, :, 100:137])),
+                         b.backward(np.ascontiguousarray(A[:, :, 137:300])), b.backward(np.ascontiguousarray(A[:, :, 300:]))], axis=1)
+    assert np.array_equal(ya, yb)
+    assert relrms(ya, o.backward(A)) < 1e-6
