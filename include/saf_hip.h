@@ -111,6 +111,15 @@ SAF_API void generateVBAPgainTable3D(float* ls_dirs_deg, int L, int az_res_deg, 
 SAF_API void compressVBAPgainTable3D(float* vbap_gtable, int nTable, int nDirs, float* vbap_gtableComp, int* vbap_gtableIdx); /* saf_vbap.h:174 */
 SAF_API void VBAPgainTable2InterpTable(float* vbap_gtable, int nTable, int nDirs);                                           /* saf_vbap.h:192 */
 SAF_API void findLsTriplets(float* ls_dirs_deg, int L, int omitLargeTriangles, float** out_vertices, int* numOutVertices, int** out_faces, int* numOutFaces); /* saf_vbap.h:328 */
+/* 2-D (horizontal) VBAP — not reached by any operator of this library (panner forces the 3-D layout, panner_internal.h:59)
+ * but part of the module's interface; host code.  Source directions are AZIMUTHS only (one float per source), as
+ * vbap2D reads them. */
+SAF_API void generateVBAPgainTable2D_srcs(float* src_dirs_deg, int S, float* ls_dirs_deg, int L, float** gtable, int* N_gtable, int* nPairs); /* saf_vbap.h:277 */
+SAF_API void generateVBAPgainTable2D(float* ls_dirs_deg, int L, int az_res_deg, float** gtable, int* N_gtable, int* nPairs);                   /* saf_vbap.h:299 */
+SAF_API void findLsPairs(float* ls_dirs_deg, int L, int** out_pairs, int* numOutPairs);                                                         /* saf_vbap.h:404 */
+SAF_API void invertLsMtx2D(float* U_spkr, int* ls_pairs, int N_pairs, float** layoutInvMtx);                                                    /* saf_vbap.h:417 */
+SAF_API void vbap2D(float* src_dirs, int src_num, int ls_num, int* ls_pairs, int N_pairs, float* layoutInvMtx, float** GainMtx);               /* saf_vbap.h:431 */
+SAF_API void getSpreadSrcDirs3D(float src_azi_rad, float src_elev_rad, float spread, int num_src, int num_rings_3d, float* U_spread);           /* saf_vbap.h:366 */
 SAF_API void invertLsMtx3D(float* U_spkr, int* ls_groups, int N_group, float** layoutInvMtx);                                /* saf_vbap.h:348 */
 SAF_API void vbap3D(float* src_dirs, int src_num, int ls_num, int* ls_groups, int nFaces, float spread, float* layoutInvMtx, float** GainMtx); /* saf_vbap.h:393 */
 

@@ -215,6 +215,35 @@ def generateVBAPgainTable3D(ls_dirs_deg, az_res, el_res, omitLarge=0, dummies=0,
     return np.ctypeslib.as_array(g, shape=(n.value, d.shape[0])).copy(), nt.value
 
 
+def generateVBAPgainTable2D(ls_dirs_deg, az_res):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    n = lib().orc_generateVBAPgainTable2D(fptr(d), d.shape[0], az_res, None)
+    g = np.zeros((n, d.shape[0]), np.float32)
+    lib().orc_generateVBAPgainTable2D(fptr(d), d.shape[0], az_res, fptr(g))
+    return g, d.shape[0]
+
+
+def generateVBAPgainTable2D_srcs(src_azi_deg, ls_dirs_deg):
+    a = np.ascontiguousarray(src_azi_deg, np.float32).reshape(-1)
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    g = np.zeros((a.shape[0], d.shape[0]), np.float32)
+    lib().orc_vbap2D_table(fptr(a), a.shape[0], fptr(d), d.shape[0], fptr(g))
+    return g, d.shape[0]
+
+
+def findLsPairs(ls_dirs_deg):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    p = np.zeros((d.shape[0], 2), np.int32)
+    lib().orc_findLsPairs(fptr(d), d.shape[0], p.ctypes.data_as(C.POINTER(C.c_int)))
+    return p
+
+
+def getSpreadSrcDirs3D(azi_rad, elev_rad, spread_deg, num_src=8, num_rings=1):
+    U = np.zeros((num_rings * num_src + 1, 3), np.float32)
+    lib().orc_getSpreadSrcDirs3D(C.c_float(azi_rad), C.c_float(elev_rad), C.c_float(spread_deg), num_src, num_rings, fptr(U))
+    return U
+
+
 def compressVBAPgainTable3D(gt):
     gt = np.ascontiguousarray(gt, np.float32)
     comp = np.zeros((gt.shape[0], 3), np.float32)

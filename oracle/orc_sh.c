@@ -905,3 +905,65 @@ void orc_getVoronoiWeights(const float* dirs_deg, int nDirs, float* weights)
     }
     free(V); free(faces); free(vert); free(dup); free(ring); free(poly); free(theta);
 }
+
+/* ---------------- 2-D VBAP (saf_vbap.c:390-473, 898-1024) ---------------- */
+/* findLsPairs: ascending azimuth order, neighbouring loudspeakers form the pairs, the last pair wraps around */
+void orc_findLsPairs(const float* ls_dirs_deg, int L, int* pairs)
+{
+    int* idx = (int*)malloc(sizeof(int) * (L + 1));
+    for (int n = 0; n < L; n++) idx[n] = n;
+    for (int i = 1; i < L; i++) {                      /* insertion sort (stable) */
+        int k = idx[i], j = i - 1;
+        while (j >= 0 && ls_dirs_deg[idx[j] * 2] > ls_dirs_deg[k * 2]) { idx[j + 1] = idx[j]; j--; }
+        idx[j + 1] = k;
+    }
+    idx[L] = idx[0];
+    for (int n = 0; n < L; n++) { pairs[n * 2] = idx[n]; pairs[n * 2 + 1] = idx[n + 1]; }
+    free(idx);
+}
+
+/* generateVBAPgainTable2D_srcs / vbap2D on S azimuths: gtable is [S][L] (caller-allocated here) */
+void orc_vbap2D_table(const float* src_azi_deg, int S, const float* ls_dirs_deg, int L, float* gtable)
+{
+    int* pairs = (int*)malloc(sizeof(int) * 2 * L);
+    orc_findLsPairs(ls_dirs_deg, L, pairs);
+    float* inv = (float*)malloc(sizeof(float) * 4 * L);
+    for (int n = 0; n < L; n++) {
+        /* tempGroup[j*2+i] = U[pair_i][j]: columns = unit vectors of the pair; invertLsMtx2D stores the inverse row-major */
+        float m00 = cosf(ls_dirs_deg[pairs[n * 2] * 2] * ORC_PI / 180.0f), m10 = sinf(ls_dirs_deg[pairs[n * 2] * 2] * ORC_PI / 180.0f);
+        float m01 = cosf(ls_dirs_deg[pairs[n * 2 + 1] * 2] * ORC_PI / 180.0f), m11 = sinf(ls_dirs_deg[pairs[n * 2 + 1] * 2] * ORC_PI / 180.0f);
+        double det = (double)m00 * m11 - (double)m01 * m10;
+        inv[n * 4 + 0] = (float)(m11 / det); inv[n * 4 + 1] = (float)(-m01 / det);
+        inv[n * 4 + 2] = (float)(-m10 / det); inv[n * 4 + 3] = (float)(m00 / det);
+    }
+    float* gains = (float*)malloc(sizeof(float) * L);
+    for (int ns = 0; ns < S; ns++) {
+        float azi = src_azi_deg[ns] * ORC_PI / 180.0f, u0 = cosf(azi), u1 = sinf(azi);
+        memset(gains, 0, sizeof(float) * L);
+        for (int i = 0; i < L; i++) {
+            float g0 = inv[i * 4] * u0 + inv[i * 4 + 1] * u1, g1 = inv[i * 4 + 2] * u0 + inv[i * 4 + 3] * u1;
+            float mn = g0 < g1 ? g0 : g1, rms = sqrtf(powf(g0, 2.0f) + powf(g1, 2.0f));
+            if (mn > -0.001) { gains[pairs[i * 2]] = g0 / rms; gains[pairs[i * 2 + 1]] = g1 / rms; }
+        }
+        float e = 0.0f;
+        for (int i = 0; i < L; i++) e += powf(gains[i], 2.0f);
+        e = sqrtf(e);
+        for (int i = 0; i < L; i++) { float v = gains[i] / e; gtable[(size_t)ns * L + i] = v > 0.0f ? v : 0.0f; }
+    }
+    free(gains); free(inv); free(pairs);
+}
+
+/* generateVBAPgainTable2D: azimuth grid -180 : res : 180; returns the number of grid points (gtable NULL: count only) */
+int orc_generateVBAPgainTable2D(const float* ls_dirs_deg, int L, int az_res_deg, float* gtable)
+{
+    const int N_azi = (int)((360.0f / (float)az_res_deg) + 1.5f);
+    if (!gtable) return N_azi;
+    float* azi = (float*)malloc(sizeof(float) * N_azi);
+    float fi; int i;
+    for (fi = -180.0f, i = 0; i < N_azi; fi += (float)az_res_deg, i++) azi[i] = fi;
+    orc_vbap2D_table(azi, N_azi, ls_dirs_deg, L, gtable);
+    free(azi);
+    return N_azi;
+}
+
+void orc_getSpreadSrcDirs3D(float azi, float elev, float spread, int num_src, int num_rings, float* Us) { spread_dirs(azi, elev, spread, num_src, num_rings, Us); }

@@ -75,6 +75,10 @@ void orc_pinv(const float* inM, int dim1, int dim2, float* outM);  /* utility_sp
 
 /* ---- VBAP (saf_vbap.c) ---- */
 int  orc_findLsTriplets(const float* ls_dirs_deg, int L, int omitLargeTriangles, float** out_vertices, int* numOutVertices, int** out_faces, int* numOutFaces);
+void orc_findLsPairs(const float* ls_dirs_deg, int L, int* pairs /* [L][2] */);
+void orc_vbap2D_table(const float* src_azi_deg, int S, const float* ls_dirs_deg, int L, float* gtable /* [S][L] */);
+int  orc_generateVBAPgainTable2D(const float* ls_dirs_deg, int L, int az_res_deg, float* gtable /* NULL: returns the row count */);
+void orc_getSpreadSrcDirs3D(float azi, float elev, float spread, int num_src, int num_rings, float* Us);
 void orc_invertLsMtx3D(const float* U_spkr, const int* ls_groups, int N_group, float* layoutInvMtx);
 void orc_vbap3D(const float* src_dirs, int src_num, int ls_num, const int* ls_groups, int nFaces, float spread, const float* layoutInvMtx, float** GainMtx);
 void orc_generateVBAPgainTable3D_srcs(const float* src_dirs_deg, int S, const float* ls_dirs_deg, int L, int omitLargeTriangles, int enableDummies, float spread, float** gtable, int* N_gtable, int* nTriangles);

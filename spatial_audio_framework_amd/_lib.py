@@ -83,6 +83,12 @@ def load():
     sig("vbap3D", None, fp, ci, ci, ip, ci, cf, fp, C.POINTER(fp))
     sig("generateVBAPgainTable3D_srcs", None, fp, ci, fp, ci, ci, ci, cf, C.POINTER(fp), ip, ip)
     sig("generateVBAPgainTable3D", None, fp, ci, ci, ci, ci, ci, cf, C.POINTER(fp), ip, ip)
+    sig("generateVBAPgainTable2D_srcs", None, fp, ci, fp, ci, C.POINTER(fp), ip, ip)
+    sig("generateVBAPgainTable2D", None, fp, ci, ci, C.POINTER(fp), ip, ip)
+    sig("findLsPairs", None, fp, ci, C.POINTER(ip), ip)
+    sig("invertLsMtx2D", None, fp, ip, ci, C.POINTER(fp))
+    sig("vbap2D", None, fp, ci, ci, ip, ci, fp, C.POINTER(fp))
+    sig("getSpreadSrcDirs3D", None, cf, cf, cf, ci, ci, fp)
     sig("compressVBAPgainTable3D", None, fp, ci, ci, fp, ip)
     sig("VBAPgainTable2InterpTable", None, fp, ci, ci)
     # ambi_dec

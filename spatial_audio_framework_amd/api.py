@@ -190,6 +190,38 @@ def generateVBAPgainTable3D(ls_dirs_deg, az_res, el_res, omitLarge=0, dummies=0,
     return _take(g, (n.value, d.shape[0])), nt.value
 
 
+def generateVBAPgainTable2D(ls_dirs_deg, az_res):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    g = fp()
+    n, npairs = C.c_int(), C.c_int()
+    load().generateVBAPgainTable2D(_f(d), d.shape[0], az_res, C.byref(g), C.byref(n), C.byref(npairs))
+    return _take(g, (n.value, d.shape[0])), npairs.value
+
+
+def generateVBAPgainTable2D_srcs(src_azi_deg, ls_dirs_deg):
+    a = np.ascontiguousarray(src_azi_deg, np.float32).reshape(-1)
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    g = fp()
+    n, npairs = C.c_int(), C.c_int()
+    load().generateVBAPgainTable2D_srcs(_f(a), a.shape[0], _f(d), d.shape[0], C.byref(g), C.byref(n), C.byref(npairs))
+    return _take(g, (n.value, d.shape[0])), npairs.value
+
+
+def findLsPairs(ls_dirs_deg):
+    d = np.ascontiguousarray(ls_dirs_deg, np.float32).reshape(-1, 2)
+    pairs = ip(); n = C.c_int()
+    load().findLsPairs(_f(d), d.shape[0], C.byref(pairs), C.byref(n))
+    out = np.ctypeslib.as_array(pairs, shape=(n.value * 2,)).copy().reshape(n.value, 2)
+    C.CDLL(None).free(C.cast(pairs, vp))
+    return out
+
+
+def getSpreadSrcDirs3D(azi_rad, elev_rad, spread_deg, num_src=8, num_rings=1):
+    U = np.zeros((num_rings * num_src + 1, 3), np.float32)
+    load().getSpreadSrcDirs3D(C.c_float(azi_rad), C.c_float(elev_rad), C.c_float(spread_deg), num_src, num_rings, _f(U))
+    return U
+
+
 def compressVBAPgainTable3D(gt):
     gt = np.ascontiguousarray(gt, np.float32)
     comp = np.zeros((gt.shape[0], 3), np.float32)

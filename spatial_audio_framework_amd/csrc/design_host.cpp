@@ -257,7 +257,7 @@ void invert_ls_mtx(const float* U, const int* grp, int nGroups, float* inv)
 }
 
 /* getSpreadSrcDirs3D (saf_vbap.c:707-783): 8 directions on a ring + the source itself */
-static void spread_ring(float azi, float elev, float spread, int nSrc, int nRings, float* Us)
+void spread_ring(float azi, float elev, float spread, int nSrc, int nRings, float* Us)
 {
     const float u[3] = { cosf(elev) * cosf(azi), cosf(elev) * sinf(azi), sinf(elev) };
     const float theta = 2.0f * SAF_PI / (float)nSrc, st = sinf(theta), ct = cosf(theta);
@@ -581,4 +581,92 @@ void VBAPgainTable2InterpTable(float* vbap_gtable, int nTable, int nDirs)
     }
 }
 
-}  // extern "C"
+
+/* ---------------- 2-D (horizontal) VBAP and the spread ring (saf_vbap.h:277-306, 360-430) ---------------- */
+/* findLsPairs (saf_vbap.c:898-928): neighbours after sorting the azimuths; L pairs, the last one closes the circle */
+void findLsPairs(float* ls_dirs_deg, int L, int** out_pairs, int* numOutPairs)
+{
+    std::vector<int> order(L);
+    for (int n = 0; n < L; n++) order[n] = n;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ls_dirs_deg[a * 2] < ls_dirs_deg[b * 2]; });
+    *out_pairs = (int*)malloc(sizeof(int) * 2 * (size_t)std::max(L, 1));
+    for (int n = 0; n < L; n++) { (*out_pairs)[n * 2] = order[n]; (*out_pairs)[n * 2 + 1] = order[(n + 1) % L]; }
+    *numOutPairs = L;
+}
+
+/* invertLsMtx2D (saf_vbap.c:930-960): inverse of the 2 x 2 matrix whose columns are the pair's unit vectors */
+void invertLsMtx2D(float* U_spkr, int* ls_pairs, int N_pairs, float** layoutInvMtx)
+{
+    *layoutInvMtx = (float*)malloc(sizeof(float) * 4 * (size_t)std::max(N_pairs, 1));
+    for (int n = 0; n < N_pairs; n++) {
+        const double a = U_spkr[ls_pairs[n * 2] * 2], c = U_spkr[ls_pairs[n * 2] * 2 + 1];           /* first column  */
+        const double b = U_spkr[ls_pairs[n * 2 + 1] * 2], d = U_spkr[ls_pairs[n * 2 + 1] * 2 + 1];   /* second column */
+        const double r = 1.0 / (a * d - b * c);
+        float* o = *layoutInvMtx + n * 4;
+        o[0] = (float)(d * r); o[1] = (float)(-b * r); o[2] = (float)(-c * r); o[3] = (float)(a * r);
+    }
+}
+
+/* vbap2D (saf_vbap.c:962-1024): every pair whose two gains exceed -0.001 writes its (pair-normalised) gains — a later pair
+ * overwrites an earlier one on a shared loudspeaker —, then unit energy over all loudspeakers and clipping at 0.
+ * src_dirs holds AZIMUTHS only (one float per source), as the reference reads it. */
+void vbap2D(float* src_dirs, int src_num, int ls_num, int* ls_pairs, int N_pairs, float* layoutInvMtx, float** GainMtx)
+{
+    *GainMtx = (float*)malloc(sizeof(float) * (size_t)std::max(src_num, 1) * std::max(ls_num, 1));
+    std::vector<float> gains(ls_num);
+    for (int ns = 0; ns < src_num; ns++) {
+        const float azi = src_dirs[ns] * SAF_PI / 180.0f;
+        const float u[2] = { cosf(azi), sinf(azi) };
+        std::fill(gains.begin(), gains.end(), 0.0f);
+        for (int i = 0; i < N_pairs; i++) {
+            float g[2];
+            g[0] = layoutInvMtx[i * 4 + 0] * u[0] + layoutInvMtx[i * 4 + 1] * u[1];
+            g[1] = layoutInvMtx[i * 4 + 2] * u[0] + layoutInvMtx[i * 4 + 3] * u[1];
+            const float mn = std::min(g[0], g[1]);
+            const float rms = sqrtf(powf(g[0], 2.0f) + powf(g[1], 2.0f));
+            if (mn > -0.001f)
+                for (int j = 0; j < 2; j++) gains[ls_pairs[i * 2 + j]] = g[j] / rms;
+        }
+        float e = 0.0f;
+        for (int i = 0; i < ls_num; i++) e += powf(gains[i], 2.0f);
+        e = sqrtf(e);
+        for (int i = 0; i < ls_num; i++) (*GainMtx)[(size_t)ns * ls_num + i] = std::max(gains[i] / e, 0.0f);
+    }
+}
+
+static void vbap2d_table(float* src_azi, int S, float* ls_dirs_deg, int L, float** gtable, int* N_gtable, int* nPairs)
+{
+    int* pairs = nullptr; int nP = 0;
+    findLsPairs(ls_dirs_deg, L, &pairs, &nP);
+    std::vector<float> verts((size_t)L * 2);
+    for (int i = 0; i < L; i++) { verts[i * 2] = cosf(ls_dirs_deg[i * 2] * SAF_PI / 180.0f); verts[i * 2 + 1] = sinf(ls_dirs_deg[i * 2] * SAF_PI / 180.0f); }
+    float* inv = nullptr;
+    invertLsMtx2D(verts.data(), pairs, nP, &inv);
+    vbap2D(src_azi, S, L, pairs, nP, inv, gtable);
+    *nPairs = nP; *N_gtable = S;
+    free(pairs); free(inv);
+}
+
+/* generateVBAPgainTable2D_srcs (saf_vbap.c:390-426): src_dirs_deg is handed to vbap2D as it is, i.e. read as S azimuths */
+void generateVBAPgainTable2D_srcs(float* src_dirs_deg, int S, float* ls_dirs_deg, int L, float** gtable, int* N_gtable, int* nPairs)
+{
+    vbap2d_table(src_dirs_deg, S, ls_dirs_deg, L, gtable, N_gtable, nPairs);
+}
+
+/* generateVBAPgainTable2D (saf_vbap.c:428-473): azimuth grid -180 : res : 180 */
+void generateVBAPgainTable2D(float* ls_dirs_deg, int L, int az_res_deg, float** gtable, int* N_gtable, int* nPairs)
+{
+    const int N_azi = (int)((360.0f / (float)az_res_deg) + 1.5f);
+    std::vector<float> azi(N_azi);
+    float fi = -180.0f;
+    for (int i = 0; i < N_azi; fi += (float)az_res_deg, i++) azi[i] = fi;
+    vbap2d_table(azi.data(), N_azi, ls_dirs_deg, L, gtable, N_gtable, nPairs);
+}
+
+/* getSpreadSrcDirs3D (saf_vbap.c:707-783): U_spread is [(num_rings_3d * num_src + 1) x 3] */
+void getSpreadSrcDirs3D(float src_azi_rad, float src_elev_rad, float spread, int num_src, int num_rings_3d, float* U_spread)
+{
+    saf::spread_ring(src_azi_rad, src_elev_rad, spread, num_src, num_rings_3d, U_spread);
+}
+
+}

@@ -472,3 +472,17 @@ def test_afSTFT_synthesis_time_chunks_bit_identical(saf, orc):
                          b.backward(np.ascontiguousarray(A[:, :, 137:300])), b.backward(np.ascontiguousarray(A[:, :, 300:]))], axis=1)
     assert np.array_equal(ya, yb)
     assert relrms(ya, o.backward(A)) < 1e-6
+
+
+def test_vbap2d_and_spread_ring_vs_oracle(saf, orc):
+    """2-D VBAP tables and getSpreadSrcDirs3D of the library (host code) against the oracle; irregular layout."""
+    ls = np.array([[-150, 0], [30, 0], [-30, 0], [110, 0], [-110, 0], [0, 0], [175, 0]], np.float32)
+    assert np.array_equal(saf.findLsPairs(ls), orc.findLsPairs(ls))
+    for res in (1, 5):
+        g, n = saf.generateVBAPgainTable2D(ls, res)
+        o, _ = orc.generateVBAPgainTable2D(ls, res)
+        assert g.shape == o.shape and n == 7 and maxabs(g, o) < 2e-6
+    az = np.random.default_rng(3).uniform(-180, 180, 50).astype(np.float32)
+    assert maxabs(saf.generateVBAPgainTable2D_srcs(az, ls)[0], orc.generateVBAPgainTable2D_srcs(az, ls)[0]) < 2e-6
+    for a, e, sp, ns, nr in ((0.3, -0.2, 40.0, 8, 1), (2.0, 1.565, 90.0, 8, 1), (-1.0, 0.4, 30.0, 6, 2)):
+        assert maxabs(saf.getSpreadSrcDirs3D(a, e, sp, ns, nr), orc.getSpreadSrcDirs3D(a, e, sp, ns, nr)) < 2e-6

@@ -547,3 +547,30 @@ def test_binaural_ambi_decoders_closed_forms(orc):
     g = np.sqrt(pt) / np.sqrt(pq) / 10 ** (9 / 20)
     g = np.where(g > 1, 1 + np.tanh(g - 1), g) * 10 ** (9 / 20)
     assert np.abs(orc.truncationEQ(np.ones(4, np.float32), 3, 42, kr, 9.0) - g).max() < 1e-3
+
+
+def test_vbap2d_closed_forms():
+    """2-D VBAP (saf_vbap.c:390-473, 898-1024; the reference has no test for it): on a regular ring a source at a
+    loudspeaker gets gain 1 there, a source midway between two neighbours gets 1/sqrt(2) on each, every row has unit
+    energy and at most two non-zero gains, which belong to neighbouring loudspeakers."""
+    from oracle import oracle as O
+    L = 8
+    ls = np.stack([np.arange(L) * 45.0 - 180.0 + 10.0, np.zeros(L)], 1).astype(np.float32)
+    ls = ls[[3, 0, 6, 1, 7, 2, 5, 4]]                                   # unsorted on purpose
+    pairs = O.findLsPairs(ls)
+    order = np.argsort(ls[:, 0], kind="stable")
+    assert np.array_equal(pairs[:, 0], order) and np.array_equal(pairs[:, 1], np.roll(order, -1))
+    g, _ = O.generateVBAPgainTable2D_srcs(ls[:, 0], ls)
+    assert np.allclose(g, np.eye(L), atol=2e-6)
+    mid = np.sort(ls[:, 0])[:-1] + 22.5
+    g, _ = O.generateVBAPgainTable2D_srcs(mid, ls)
+    assert np.allclose(np.sort(g, 1)[:, -2:], 1 / np.sqrt(2), atol=2e-6) and np.allclose((g ** 2).sum(1), 1, atol=2e-6)
+    gt, _ = O.generateVBAPgainTable2D(ls, 2)
+    assert gt.shape == (181, L) and np.allclose((gt ** 2).sum(1), 1, atol=3e-6) and ((gt > 1e-6).sum(1) <= 2).all()
+    assert np.allclose(gt[0], gt[-1], atol=2e-6)                        # -180 and +180 are the same direction
+    # the spread ring: num_src directions at half the spread angle from the source + the source itself
+    U = O.getSpreadSrcDirs3D(0.3, -0.2, 40.0, 8, 1)
+    u = U[-1]
+    assert np.allclose(np.linalg.norm(u), 1, atol=1e-6)
+    ang = np.degrees(np.arccos(np.clip((U[:-1] @ u) / np.linalg.norm(U[:-1], axis=1), -1, 1)))
+    assert np.allclose(ang, 20.0, atol=1e-3) and np.allclose(np.linalg.norm(U[0]), 1, atol=1e-6)
