@@ -644,6 +644,9 @@ SAF_API void truncationEQ(float* w_n, int order_truncated, int order_target, dou
  *  reference (its time-alignment phase term multiplies the ITD by zero, saf_hoa_internal.c:495-498). */
 SAF_API void getBinauralAmbiDecoderMtx(float_complex* hrtfs, float* hrtf_dirs_deg, int N_dirs, int N_bands, BINAURAL_AMBI_DECODER_METHODS method, int order,
                                        float* freqVector, float* itd_s, float* weights, int enableDiffCovMatching, int enableMaxReWeighting, float_complex* decMtx);
+/** decFilters: 2 x (order+1)^2 x fftSize time-domain decoding filters; hrtfs: (fftSize/2+1) x 2 x N_dirs (saf_hoa.h:452-500). */
+SAF_API void getBinauralAmbiDecoderFilters(float_complex* hrtfs, float* hrtf_dirs_deg, int N_dirs, int fftSize, float fs, BINAURAL_AMBI_DECODER_METHODS method, int order,
+                                           float* itd_s, float* weights, int enableDiffCovMatching, int enableMaxReWeighting, float* decFilters);
 SAF_API void applyDiffCovMatching(float_complex* hrtfs, float* hrtf_dirs_deg, int N_dirs, int N_bands, int order, float* weights, float_complex* decMtx);   /* saf_hoa.c:502 */
 /** Replaces -DAMBI_BIN_FRAME_SIZE; call before ambi_bin_create. */
 SAF_API void saf_hip_ambi_bin_setFrameSize(int frameSize);

@@ -628,6 +628,17 @@ def getBinauralAmbiDecoderMtx(hrtfs, dirs_deg, method, order, freqVector=None, i
     return out
 
 
+def getBinauralAmbiDecoderFilters(hrtfs, dirs_deg, fftSize, fs, method, order, itd_s=None, weights=None, diffMatching=0, maxRE=0):
+    H = np.ascontiguousarray(hrtfs, np.complex64); nBins, _, N = H.shape
+    d = np.ascontiguousarray(dirs_deg, np.float32)
+    it = np.ascontiguousarray(itd_s if itd_s is not None else np.zeros(N), np.float32)
+    w = np.ascontiguousarray(weights, np.float32) if weights is not None else None
+    out = np.zeros((2, (order + 1) ** 2, fftSize), np.float32)
+    lib().orc_getBinauralAmbiDecoderFilters(H.ctypes.data_as(vp), fptr(d), N, fftSize, C.c_float(fs), method, order, fptr(it), fptr(w) if w is not None else None,
+                                            diffMatching, maxRE, fptr(out))
+    return out
+
+
 def truncationEQ(w_n, order_truncated, order_target, kr, softThreshold):
     w = np.ascontiguousarray(w_n, np.float32); k = np.ascontiguousarray(kr, np.float64); g = np.zeros(k.shape[0], np.float32)
     lib().orc_truncationEQ(fptr(w), order_truncated, order_target, k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], C.c_float(softThreshold), fptr(g))

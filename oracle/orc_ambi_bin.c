@@ -536,3 +536,24 @@ void orc_ambi_bin_setPitch(void* h, float v) { PA; p->ypr[1] = (p->flip[1] ? -1.
 void orc_ambi_bin_setRoll(void* h, float v) { PA; p->ypr[2] = (p->flip[2] ? -1.0f : 1.0f) * (v * ORC_PI / 180.0f); p->recalcRot = 1; }
 void orc_ambi_bin_setRPYflag(void* h, int s) { PA; p->useRPY = s; }
 const orc_cpx* orc_ambi_bin_getDecMtx(void* h) { PA; return p->M_dec; }
+
+/* getBinauralAmbiDecoderFilters (saf_hoa.c:452-500) */
+void orc_getBinauralAmbiDecoderFilters(const orc_cpx* hrtfs, const float* dirs_deg, int N, int fftSize, float fs, int method, int order,
+                                       const float* itd_s, const float* weights, int diffMatching, int maxRE, float* decFilters)
+{
+    const int nBins = fftSize / 2 + 1, nSH = (order + 1) * (order + 1);
+    float* fv = (float*)malloc(sizeof(float) * nBins);
+    for (int k = 0; k < nBins; k++) fv[k] = (float)k * fs / (float)fftSize;
+    orc_cpx* dec = (orc_cpx*)malloc(sizeof(orc_cpx) * (size_t)nBins * 2 * nSH);
+    orc_cpx* b = (orc_cpx*)malloc(sizeof(orc_cpx) * nBins);
+    orc_getBinauralAmbiDecoderMtx(hrtfs, dirs_deg, N, nBins, method, order, fv, itd_s, weights, diffMatching, maxRE, dec);
+    void* h = NULL;
+    orc_rfft_create(&h, fftSize);
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < nSH; j++) {
+            for (int k = 0; k < nBins; k++) b[k] = dec[(size_t)k * 2 * nSH + i * nSH + j];
+            orc_rfft_backward(h, b, decFilters + ((size_t)i * nSH + j) * fftSize);
+        }
+    orc_rfft_destroy(&h);
+    free(fv); free(dec); free(b);
+}

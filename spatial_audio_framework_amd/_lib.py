@@ -250,6 +250,7 @@ def load():
     sig("beamWeightsMaxEV", None, ci, fp)
     sig("truncationEQ", None, fp, ci, ci, C.POINTER(C.c_double), ci, cf, fp)
     sig("getBinauralAmbiDecoderMtx", None, vp, fp, ci, ci, ci, ci, fp, fp, fp, ci, ci, vp)
+    sig("getBinauralAmbiDecoderFilters", None, vp, fp, ci, ci, cf, ci, ci, fp, fp, ci, ci, fp)
     sig("applyDiffCovMatching", None, vp, fp, ci, ci, ci, fp, vp)
     sig("saf_hip_ambi_bin_setFrameSize", None, ci)
     sig("ambi_bin_create", None, C.POINTER(vp)); sig("ambi_bin_destroy", None, C.POINTER(vp))

@@ -414,4 +414,26 @@ void truncationEQ(float* w_n, int order_truncated, int order_target, double* kr,
     }
 }
 
+
+/* getBinauralAmbiDecoderFilters (saf_hoa.h:452-500 / saf_hoa.c:452-500): the decoder per uniformly spaced bin
+ * (getUniformFreqVector, saf_utility_fft.c:145-155), then one inverse real FFT per (ear, SH channel).
+ * hrtfs: (fftSize/2+1) x 2 x N_dirs; decFilters: 2 x nSH x fftSize. */
+void getBinauralAmbiDecoderFilters(float_complex* hrtfs, float* hrtf_dirs_deg, int N_dirs, int fftSize, float fs, BINAURAL_AMBI_DECODER_METHODS method, int order,
+                                   float* itd_s, float* weights, int enableDiffCovMatching, int enableMaxReWeighting, float* decFilters)
+{
+    const int nBins = fftSize / 2 + 1, nSH = (order + 1) * (order + 1);
+    std::vector<float> freq(nBins);
+    for (int k = 0; k < nBins; k++) freq[k] = (float)k * fs / (float)fftSize;
+    std::vector<float_complex> dec((size_t)nBins * 2 * nSH), bins(nBins);
+    getBinauralAmbiDecoderMtx(hrtfs, hrtf_dirs_deg, N_dirs, nBins, method, order, freq.data(), itd_s, weights, enableDiffCovMatching, enableMaxReWeighting, dec.data());
+    void* hFFT = nullptr;
+    saf_rfft_create(&hFFT, fftSize);
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < nSH; j++) {
+            for (int k = 0; k < nBins; k++) bins[k] = dec[(size_t)k * 2 * nSH + i * nSH + j];
+            saf_rfft_backward(hFFT, bins.data(), decFilters + ((size_t)i * nSH + j) * fftSize);
+        }
+    saf_rfft_destroy(&hFFT);
+}
+
 }

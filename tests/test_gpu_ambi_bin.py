@@ -124,3 +124,23 @@ def test_ambi_bin_reference_example_test_on_gpu(saf, orc, hrirs):
     out = np.concatenate([a.process(np.ascontiguousarray(sh[:, i * F:(i + 1) * F]), 2) for i in range(sh.shape[1] // F)], 1)
     tail = out[:, 20 * F:]
     assert float((tail[1] ** 2).sum()) > 4.0 * float((tail[0] ** 2).sum())
+
+
+@pytest.mark.parametrize("method,order,fftSize", [(1, 3, 256), (3, 2, 128), (5, 3, 240)])
+def test_decoder_filters_vs_oracle_and_against_the_matrix(saf, orc, hrirs, method, order, fftSize):
+    """getBinauralAmbiDecoderFilters (saf_hoa.c:452-500): HRTFs = real FFT of the synthetic HRIRs (so the filters are real),
+    the library against the oracle, and the filters' forward FFT gives back the per-bin decoding matrix (Im of DC and
+    Nyquist dropped by the C2R transform, saf_utility_fft.c:728-753)."""
+    h, d = hrirs
+    H = np.fft.rfft(h[:, :, :fftSize].astype(np.float64), n=fftSize, axis=2)            # [N][2][bins]
+    H = np.ascontiguousarray(np.transpose(H, (2, 1, 0))).astype(np.complex64)            # [bins][2][N]
+    w = orc.getVoronoiWeights(d)
+    fg = saf.getBinauralAmbiDecoderFilters(H, d, fftSize, 48000.0, method, order, None, w, 0, 1)
+    fo = orc.getBinauralAmbiDecoderFilters(H, d, fftSize, 48000.0, method, order, None, w, 0, 1)
+    assert fg.shape == (2, (order + 1) ** 2, fftSize) and np.abs(fo).max() > 1e-3
+    assert relrms(fg, fo) < (3e-5 if method == 5 else TOL)
+    fv = (np.arange(fftSize // 2 + 1) * 48000.0 / fftSize).astype(np.float32)
+    D = saf.getBinauralAmbiDecoderMtx(H, d, method, order, fv, None, w, 0, 1)            # [bins][2][nSH]
+    back = np.transpose(np.fft.rfft(fg.astype(np.float64), axis=2), (2, 0, 1))
+    D = D.astype(np.complex128); D[0] = D[0].real; D[-1] = D[-1].real
+    assert relrms(back, D) < 1e-5
