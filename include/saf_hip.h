@@ -32,6 +32,10 @@ typedef float _Complex float_complex;          /* saf_utility_complex.h:70 */
 /*                                 runtime                                    */
 /* ========================================================================== */
 /** Adopt a caller-owned hipStream_t (NULL: library-owned stream). All library work is enqueued on it. */
+/** One-block host-pointer calls (X_process, saf_matrixConv_apply, ...) let the kernels read / write the library's pinned
+ *  staging blocks directly instead of copying them to and from device memory (default 1; env SAF_HIP_ZERO_COPY). */
+SAF_API void saf_hip_setZeroCopyIO(int enable);
+SAF_API int  saf_hip_getZeroCopyIO(void);
 SAF_API void  saf_hip_set_stream(void* hipStream);
 SAF_API void* saf_hip_get_stream(void);
 SAF_API void  saf_hip_synchronize(void);

@@ -44,6 +44,7 @@ def load():
         f.argtypes = list(args)
 
     sig("saf_hip_set_stream", None, vp)
+    sig("saf_hip_setZeroCopyIO", None, ci); sig("saf_hip_getZeroCopyIO", ci)
     sig("saf_hip_get_stream", vp)
     sig("saf_hip_synchronize", None)
     sig("saf_hip_device_count", ci)

@@ -272,9 +272,12 @@ void ambi_bin_process(void* const hAmbi, const float* const* inputs, float** con
         int i;
         for (i = 0; i < (nSH < nInputs ? nSH : nInputs); i++) memcpy(p->h_in.p + (size_t)i * F, inputs[i], sizeof(float) * F);
         for (; i < nRows; i++) memset(p->h_in.p + (size_t)i * F, 0, sizeof(float) * F);
-        HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nRows * F, hipMemcpyHostToDevice, stream()));
-        process_dev(p, p->d_in.p, 0, F, nRows, p->d_out.p, 0, F, 1);
-        HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)2 * F, hipMemcpyDeviceToHost, stream()));
+        if (zero_copy_io()) process_dev(p, p->h_in.p, 0, F, nRows, p->h_out.p, 0, F, 1);                  /* kernels on the pinned blocks */
+        else {
+            HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nRows * F, hipMemcpyHostToDevice, stream()));
+            process_dev(p, p->d_in.p, 0, F, nRows, p->d_out.p, 0, F, 1);
+            HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)2 * F, hipMemcpyDeviceToHost, stream()));
+        }
         HIP_CHECK(hipStreamSynchronize(stream()));
         int ch;
         for (ch = 0; ch < (2 < nOutputs ? 2 : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);

@@ -587,10 +587,17 @@ void ambi_dec_process(void* const hAmbi, const float* const* inputs, float** con
         /* a FuMa gather may read rows up to 3: make them defined */
         for (; i < (nSH < 4 ? 4 : nSH) && i < SAF_MAXCH; i++) memset(p->h_in.p + (size_t)i * F, 0, sizeof(float) * F);
         const int nRows = (nSH < 4 ? 4 : nSH);
-        HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nRows * F, hipMemcpyHostToDevice, stream()));
-        p->pipe->process(p->d_in.p, 0, 0, F, nRows, p->d_out.p, 0, 0, F, 1);
         const int nOutCh = p->binauraliseLS ? 2 : nLS;                     /* NUM_EARS or the loudspeakers (ambi_dec.c:570) */
-        HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nOutCh * F, hipMemcpyDeviceToHost, stream()));
+        if (zero_copy_io()) {
+            /* one block: the kernels read the pinned input and write the pinned output directly (hipHostMalloc memory is
+             * device-accessible): every sample crosses the link once, and the two DMA copies with their latencies drop
+             * out of the dependent chain */
+            p->pipe->process(p->h_in.p, 0, 0, F, nRows, p->h_out.p, 0, 0, F, 1);
+        } else {
+            HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nRows * F, hipMemcpyHostToDevice, stream()));
+            p->pipe->process(p->d_in.p, 0, 0, F, nRows, p->d_out.p, 0, 0, F, 1);
+            HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nOutCh * F, hipMemcpyDeviceToHost, stream()));
+        }
         HIP_CHECK(hipStreamSynchronize(stream()));
         int ch;
         for (ch = 0; ch < (nOutCh < nOutputs ? nOutCh : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);

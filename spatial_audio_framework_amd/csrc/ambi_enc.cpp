@@ -198,9 +198,12 @@ void ambi_enc_process(void* const hAmbi, const float* const* inputs, float** con
     p->h_in.ensure((size_t)SAF_MAXCH * F); p->h_out.ensure((size_t)SAF_MAXCH * F);
     if (!p->d_in.p) { p->d_in.alloc((size_t)SAF_MAXCH * F); p->d_out.alloc((size_t)SAF_MAXCH * F); }
     for (int ch = 0; ch < nIn; ch++) memcpy(p->h_in.p + (size_t)ch * F, inputs[ch], sizeof(float) * F);
-    if (nIn) HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nIn * F, hipMemcpyHostToDevice, stream()));
-    p->pipe->process(p->d_in.p, 0, 0, F, nIn, p->d_out.p, 0, 0, F, nOut, 1);
-    if (nOut) HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nOut * F, hipMemcpyDeviceToHost, stream()));
+    if (zero_copy_io()) p->pipe->process(p->h_in.p, 0, 0, F, nIn, p->h_out.p, 0, 0, F, nOut, 1);      /* kernels on the pinned blocks */
+    else {
+        if (nIn) HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nIn * F, hipMemcpyHostToDevice, stream()));
+        p->pipe->process(p->d_in.p, 0, 0, F, nIn, p->d_out.p, 0, 0, F, nOut, 1);
+        if (nOut) HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nOut * F, hipMemcpyDeviceToHost, stream()));
+    }
     HIP_CHECK(hipStreamSynchronize(stream()));
     for (int ch = 0; ch < nOut; ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);
     for (int ch = nOut; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);

@@ -434,13 +434,16 @@ void binauraliser_process(void* const hBin, const float* const* inputs, float** 
         p->h_in.ensure((size_t)p->maxSrc * F); p->h_out.ensure((size_t)2 * F);
         if (p->d_in.n < (size_t)p->maxSrc * F) p->d_in.alloc((size_t)p->maxSrc * F, true);
         for (int i = 0; i < nIn; i++) memcpy(p->h_in.p + (size_t)i * F, inputs[i], sizeof(float) * F);
-        if (nIn) HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nIn * F, hipMemcpyHostToDevice, stream()));
         DevBuf<float>& o = p->d_out;
         if (o.n < (size_t)2 * F) o.alloc((size_t)2 * F, false);
         /* always synthesise both ears; the copy-out below honours nOutputs (binauraliser.c:274-277) */
-        float* d_o = o.p;
-        process_dev(p, p->d_in.p, 0, F, nIn, d_o, 0, F, 2, 1);
-        HIP_CHECK(hipMemcpyAsync(p->h_out.p, d_o, sizeof(float) * (size_t)2 * F, hipMemcpyDeviceToHost, stream()));
+        if (zero_copy_io()) process_dev(p, p->h_in.p, 0, F, nIn, p->h_out.p, 0, F, 2, 1);                 /* kernels on the pinned blocks */
+        else {
+            if (nIn) HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nIn * F, hipMemcpyHostToDevice, stream()));
+            float* d_o = o.p;
+            process_dev(p, p->d_in.p, 0, F, nIn, d_o, 0, F, 2, 1);
+            HIP_CHECK(hipMemcpyAsync(p->h_out.p, d_o, sizeof(float) * (size_t)2 * F, hipMemcpyDeviceToHost, stream()));
+        }
         HIP_CHECK(hipStreamSynchronize(stream()));
         int ch;
         for (ch = 0; ch < (2 < nOutputs ? 2 : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);

@@ -197,9 +197,12 @@ void saf_matrixConv_apply(void* const hMC, float* inputSig, float* outputSig)
     h->h_in.ensure(nin); h->h_out.ensure(nout);
     if (!h->d_in.p) { h->d_in.alloc(nin, false); h->d_out.alloc(nout, false); }
     memcpy(h->h_in.p, inputSig, sizeof(float) * nin);
-    HIP_CHECK(hipMemcpyAsync(h->d_in.p, h->h_in.p, sizeof(float) * nin, hipMemcpyHostToDevice, stream()));
-    h->apply_dev(h->d_in.p, h->hop, 0, h->d_out.p, h->hop, 0, 1);
-    HIP_CHECK(hipMemcpyAsync(h->h_out.p, h->d_out.p, sizeof(float) * nout, hipMemcpyDeviceToHost, stream()));
+    if (zero_copy_io()) h->apply_dev(h->h_in.p, h->hop, 0, h->h_out.p, h->hop, 0, 1);                    /* kernels on the pinned blocks */
+    else {
+        HIP_CHECK(hipMemcpyAsync(h->d_in.p, h->h_in.p, sizeof(float) * nin, hipMemcpyHostToDevice, stream()));
+        h->apply_dev(h->d_in.p, h->hop, 0, h->d_out.p, h->hop, 0, 1);
+        HIP_CHECK(hipMemcpyAsync(h->h_out.p, h->d_out.p, sizeof(float) * nout, hipMemcpyDeviceToHost, stream()));
+    }
     HIP_CHECK(hipStreamSynchronize(stream()));
     memcpy(outputSig, h->h_out.p, sizeof(float) * nout);
 }
@@ -226,9 +229,12 @@ void saf_multiConv_apply(void* const hMC, float* inputSig, float* outputSig)
     h->h_in.ensure(n); h->h_out.ensure(n);
     if (!h->d_in.p) { h->d_in.alloc(n, false); h->d_out.alloc(n, false); }
     memcpy(h->h_in.p, inputSig, sizeof(float) * n);
-    HIP_CHECK(hipMemcpyAsync(h->d_in.p, h->h_in.p, sizeof(float) * n, hipMemcpyHostToDevice, stream()));
-    h->apply_dev(h->d_in.p, h->hop, 0, h->d_out.p, h->hop, 0, 1);
-    HIP_CHECK(hipMemcpyAsync(h->h_out.p, h->d_out.p, sizeof(float) * n, hipMemcpyDeviceToHost, stream()));
+    if (zero_copy_io()) h->apply_dev(h->h_in.p, h->hop, 0, h->h_out.p, h->hop, 0, 1);
+    else {
+        HIP_CHECK(hipMemcpyAsync(h->d_in.p, h->h_in.p, sizeof(float) * n, hipMemcpyHostToDevice, stream()));
+        h->apply_dev(h->d_in.p, h->hop, 0, h->d_out.p, h->hop, 0, 1);
+        HIP_CHECK(hipMemcpyAsync(h->h_out.p, h->d_out.p, sizeof(float) * n, hipMemcpyDeviceToHost, stream()));
+    }
     HIP_CHECK(hipStreamSynchronize(stream()));
     memcpy(outputSig, h->h_out.p, sizeof(float) * n);
 }
@@ -261,9 +267,12 @@ void saf_TVConv_apply(void* const hTVC, float* inputSig, float* outputSig, int i
     h->h_in.ensure(nin); h->h_out.ensure(nout);
     if (!h->d_in.p) { h->d_in.alloc(nin, false); h->d_out.alloc(nout, false); }
     memcpy(h->h_in.p, inputSig, sizeof(float) * nin);
-    HIP_CHECK(hipMemcpyAsync(h->d_in.p, h->h_in.p, sizeof(float) * nin, hipMemcpyHostToDevice, stream()));
-    h->apply_dev(h->d_in.p, 0, h->d_out.p, h->hop, 0, &irIdx, 1);
-    HIP_CHECK(hipMemcpyAsync(h->h_out.p, h->d_out.p, sizeof(float) * nout, hipMemcpyDeviceToHost, stream()));
+    if (zero_copy_io()) h->apply_dev(h->h_in.p, 0, h->h_out.p, h->hop, 0, &irIdx, 1);
+    else {
+        HIP_CHECK(hipMemcpyAsync(h->d_in.p, h->h_in.p, sizeof(float) * nin, hipMemcpyHostToDevice, stream()));
+        h->apply_dev(h->d_in.p, 0, h->d_out.p, h->hop, 0, &irIdx, 1);
+        HIP_CHECK(hipMemcpyAsync(h->h_out.p, h->d_out.p, sizeof(float) * nout, hipMemcpyDeviceToHost, stream()));
+    }
     HIP_CHECK(hipStreamSynchronize(stream()));
     memcpy(outputSig, h->h_out.p, sizeof(float) * nout);
 }

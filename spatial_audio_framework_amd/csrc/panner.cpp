@@ -310,9 +310,12 @@ void panner_process(void* const hPan, const float* const* inputs, float** const 
         p->h_in.ensure((size_t)SAF_MAXCH * F); p->h_out.ensure((size_t)SAF_MAXCH * F);
         if (p->d_in.n < (size_t)SAF_MAXCH * F) { p->d_in.alloc((size_t)SAF_MAXCH * F, true); p->d_out.alloc((size_t)SAF_MAXCH * F, true); }
         for (int i = 0; i < nIn; i++) memcpy(p->h_in.p + (size_t)i * F, inputs[i], sizeof(float) * F);
-        if (nIn) HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nIn * F, hipMemcpyHostToDevice, stream()));
-        process_dev(p, p->d_in.p, 0, F, nIn, p->d_out.p, 0, F, 1);
-        HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nL * F, hipMemcpyDeviceToHost, stream()));
+        if (zero_copy_io()) process_dev(p, p->h_in.p, 0, F, nIn, p->h_out.p, 0, F, 1);                    /* kernels on the pinned blocks */
+        else {
+            if (nIn) HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nIn * F, hipMemcpyHostToDevice, stream()));
+            process_dev(p, p->d_in.p, 0, F, nIn, p->d_out.p, 0, F, 1);
+            HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nL * F, hipMemcpyDeviceToHost, stream()));
+        }
         HIP_CHECK(hipStreamSynchronize(stream()));
         int ch;
         for (ch = 0; ch < (nL < nOutputs ? nL : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);

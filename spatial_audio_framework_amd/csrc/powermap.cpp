@@ -281,8 +281,11 @@ void powermap_analysis(void* const hPm, const float* const* inputs, int nInputs,
             p->h_in.ensure((size_t)SAF_MAXCH * F);
             if (p->d_in.n < (size_t)SAF_MAXCH * F) p->d_in.alloc((size_t)SAF_MAXCH * F, true);
             memcpy(p->h_in.p, p->inFIFO.data(), sizeof(float) * (size_t)rows * F);
-            HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)rows * F, hipMemcpyHostToDevice, stream()));
-            analyse_frames_dev(p, p->d_in.p, 0, F, rows, 1);
+            if (zero_copy_io()) analyse_frames_dev(p, p->h_in.p, 0, F, rows, 1);                             /* kernels on the pinned block */
+            else {
+                HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)rows * F, hipMemcpyHostToDevice, stream()));
+                analyse_frames_dev(p, p->d_in.p, 0, F, rows, 1);
+            }
             HIP_CHECK(hipStreamSynchronize(stream()));         /* h_in is reused by the next frame */
         } else if (p->FIFO_idx >= F) p->FIFO_idx = 0;
     }

@@ -42,6 +42,10 @@ void set_stream(hipStream_t s)
     if (!g_stream) { HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking)); g_own_stream = true; }
 }
 
+/* ---- host-pointer entry points: zero-copy I/O ---- */
+static int g_zero_copy = []() { const char* e = getenv("SAF_HIP_ZERO_COPY"); return e ? atoi(e) != 0 : 1; }();
+bool zero_copy_io() { return g_zero_copy != 0; }
+
 /* ---- per-kernel timing ---- */
 struct ProfRec { const char* name; hipEvent_t a, b; };
 static bool g_prof = false;
@@ -83,6 +87,8 @@ int saf_hip_profile_read(const char* name, double* total_ms)
     return n;
 }
 
+void saf_hip_setZeroCopyIO(int enable) { saf::g_zero_copy = enable ? 1 : 0; }
+int saf_hip_getZeroCopyIO(void) { return saf::g_zero_copy; }
 void saf_hip_set_stream(void* hipStream) { saf::set_stream((hipStream_t)hipStream); }
 void* saf_hip_get_stream(void) { return (void*)saf::stream(); }
 void saf_hip_synchronize(void) { HIP_CHECK(hipStreamSynchronize(saf::stream())); }

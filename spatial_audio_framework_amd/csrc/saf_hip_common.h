@@ -49,6 +49,12 @@ hipStream_t stream();                 /* stream all library work is enqueued on 
 void        set_stream(hipStream_t);  /* adopt a caller's stream (e.g. torch's current stream) */
 void        ensure_device();          /* aborts with a clear message when no GPU is usable */
 
+/* ---- host-pointer entry points (runtime.cpp) ---- */
+/* One-block host-pointer calls (X_process, saf_matrixConv_apply ...): the kernels read the pinned input block and write
+ * the pinned output block directly (hipHostMalloc memory is device-accessible) instead of two DMA copies in the
+ * dependent chain: every sample still crosses the link once.  Default on; env SAF_HIP_ZERO_COPY=0 / saf_hip_setZeroCopyIO(0). */
+bool zero_copy_io();
+
 /* ---- optional per-kernel timing with HIP events on the library stream (runtime.cpp) ---- */
 struct KernelTimer {            /* RAII: brackets one kernel launch when profiling is enabled */
     explicit KernelTimer(const char* name);

@@ -34,22 +34,36 @@ def main():
         y = np.zeros((nOut, F), np.float32)
         px, py = api._rows(x), api._rows(y)
         return lambda: fn(h, px, py, x.shape[0], nOut, F), (x, y, px, py)
-    for F in (128, 512):
-        d = api.AmbiDec(F)
-        d.setNormType(1); d.setChOrder(1); d.setMasterDecOrder(7); d.setOutputConfigPreset(29)
-        d.setDecMethod(0, 1); d.setDecMethod(1, 1); d.initCodec(); d.init(48000); d.setDecOrderAllBands(7)
-        x = frames(1, 64, F)
-        call, keep = direct(L.ambi_dec_process, d.h, x, 64, F)
-        r = lat(call); r["op"] = f"ambi_dec_process order 7 -> 64 loudspeakers, F = {F}"; r["block_us"] = round(F / 48000 * 1e6, 1); out.append(r)
-    e = api.AmbiEnc(256); e.init(48000); e.setOutputOrder(1); e.setNumSources(4)
-    x = frames(2, 4, 256)
-    call, keep = direct(L.ambi_enc_process, e.h, x, 4, 256)
-    r = lat(call); r["op"] = "ambi_enc_process 4 sources, order 1, F = 256"; r["block_us"] = round(256 / 48000 * 1e6, 1); out.append(r)
+
     h, dd = synth_hrirs()
-    b = api.Binauraliser(128, 64); b.setHRIRs(h, dd, 48000); b.init(48000); b.setNumSources(64); b.initCodec()
-    x = frames(3, 64, 128)
-    call, keep = direct(L.binauraliser_process, b.h, x, 2, 128)
-    r = lat(call); r["op"] = "binauraliser_process 64 sources, F = 128"; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+    for zc in (1, 0):
+        L.saf_hip_setZeroCopyIO(zc)
+        tag = "" if zc else " (staged copies: SAF_HIP_ZERO_COPY=0)"
+        for F in (128, 512):
+            d = api.AmbiDec(F)
+            d.setNormType(1); d.setChOrder(1); d.setMasterDecOrder(7); d.setOutputConfigPreset(29)
+            d.setDecMethod(0, 1); d.setDecMethod(1, 1); d.initCodec(); d.init(48000); d.setDecOrderAllBands(7)
+            x = frames(1, 64, F)
+            call, keep = direct(L.ambi_dec_process, d.h, x, 64, F)
+            r = lat(call); r["op"] = f"ambi_dec_process order 7 -> 64 loudspeakers, F = {F}" + tag; r["block_us"] = round(F / 48000 * 1e6, 1); out.append(r)
+        e = api.AmbiEnc(256); e.init(48000); e.setOutputOrder(1); e.setNumSources(4)
+        x = frames(2, 4, 256)
+        call, keep = direct(L.ambi_enc_process, e.h, x, 4, 256)
+        r = lat(call); r["op"] = "ambi_enc_process 4 sources, order 1, F = 256" + tag; r["block_us"] = round(256 / 48000 * 1e6, 1); out.append(r)
+        b = api.Binauraliser(128, 64); b.setHRIRs(h, dd, 48000); b.init(48000); b.setNumSources(64); b.initCodec()
+        x = frames(3, 64, 128)
+        call, keep = direct(L.binauraliser_process, b.h, x, 2, 128)
+        r = lat(call); r["op"] = "binauraliser_process 64 sources, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        pn = api.Panner(128); pn.setOutputConfigPreset(29); pn.setInputConfigPreset(30); pn.setNumSources(32); pn.initCodec(); pn.init(48000)
+        x = frames(4, 32, 128)
+        call, keep = direct(L.panner_process, pn.h, x, 64, 128)
+        r = lat(call); r["op"] = "panner_process 32 sources -> 64 loudspeakers, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        H = (np.random.default_rng(3).normal(size=(2, 256, 1024)) / 32).astype(np.float32)
+        mc = api.MatrixConv(512, H, 1)
+        xi = np.ascontiguousarray(frames(5, 256, 512)); yo = np.zeros((2, 512), np.float32)
+        fpx, fpy = xi.ctypes.data_as(api.fp), yo.ctypes.data_as(api.fp)
+        r = lat(lambda: L.saf_matrixConv_apply(mc.h, fpx, fpy)); r["op"] = "saf_matrixConv_apply 256 -> 2, 1024 taps, hop 512" + tag; r["block_us"] = round(512 / 48000 * 1e6, 1); out.append(r)
+    L.saf_hip_setZeroCopyIO(1)
     for o in out:
         print(json.dumps(o))
 
