@@ -33,21 +33,30 @@ __device__ __forceinline__ float2 cdivf(float2 a, float2 b)
 
 struct AdArgs { AdaptMapLaunch l; };
 
-/* grid 16 x 256: all 64 x 64 entries, zero outside the leading nM x nM block */
+/* grid (64 rows); 256 threads = 64 columns x 4 band groups; zero outside the leading nM x nM block.  Unconditional
+ * loads with a select (see cgrp_kernel in powermap_kernels.hip); contiguous band ranges summed in ascending order, the
+ * four partial sums added in group order. */
 __global__ __launch_bounds__(256) void cgrp_cplx_kernel(AdArgs a)
 {
+    __shared__ float2 s_p[4][64];
     const AdaptMapLaunch& l = a.l;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int i = e >> 6, j = e & 63;
+    const int i = blockIdx.x, j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int per = (l.nBands + 3) / 4;
+    const int b0 = g * per, b1 = b0 + per < l.nBands ? b0 + per : l.nBands;
     float re = 0.0f, im = 0.0f;
-    for (int band = 0; band < l.nBands; band++) {
+    const float2* Ce = l.Cx + i * 64 + j;
+#pragma unroll 17
+    for (int band = b0; band < b1; band++) {
         const int ns = l.bandNSH[band];
-        if (i < ns && j < ns) {
-            const float2 c = l.Cx[(long long)band * 64 * 64 + i * 64 + j];
-            re += c.x * l.bandScale[band]; im += c.y * l.bandScale[band];
-        }
+        const float2 c = Ce[(long long)band * 64 * 64];
+        const float sc = l.bandScale[band];
+        const bool on = i < ns && j < ns;
+        re += on ? c.x * sc : 0.0f; im += on ? c.y * sc : 0.0f;
     }
-    l.Cg[i * 64 + j] = make_float2(re, im);
+    s_p[g][j] = make_float2(re, im);
+    __syncthreads();
+    if (g == 0)
+        l.Cg[i * 64 + j] = make_float2(((s_p[0][j].x + s_p[1][j].x) + s_p[2][j].x) + s_p[3][j].x, ((s_p[0][j].y + s_p[1][j].y) + s_p[2][j].y) + s_p[3][j].y);
 }
 
 /* one workgroup, 256 threads.  status[0] = 1 when trace > 1e-8 and the factorisation succeeded, else 0 (map = 0) */
@@ -368,7 +377,7 @@ void launch_adaptive_map(const AdaptMapLaunch& l)
     }
     const int n = l.nM;
     KernelTimer kt("adaptive_map");
-    hipLaunchKernelGGL(cgrp_cplx_kernel, dim3(16), dim3(256), 0, stream(), a);
+    hipLaunchKernelGGL(cgrp_cplx_kernel, dim3(64), dim3(256), 0, stream(), a);
     if (l.mode == 2 || l.mode == 3) {
         hipLaunchKernelGGL(chol_kernel, dim3(1), dim3(256), sizeof(zc) * 64 * 65, stream(), a);
         if (l.mode == 2)

@@ -33,13 +33,31 @@ __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
         for (int v = 0; v < 4; v++) c[u][v] = (bi + u < nSH && bj + v < nSH) ? C[(bi + u) * 64 + bj + v] : make_float2(0.f, 0.f);
     const float2* X = l.X + (long long)band * l.x_band;
     const float al = l.alpha, be = 1.0f - l.alpha;
+    /* this thread's elements of a frame's [64 x T] tile (T <= 16: at most 4 per thread); loads are unconditional (rows
+     * beyond nSH re-read row nSH-1 and are zeroed) and the NEXT frame's are issued before the current frame is multiplied */
+    int tch[4], tt[4]; bool ton[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int idx = tid + 256 * q;
+        ton[q] = idx < 64 * T;
+        tch[q] = ton[q] ? idx / T : 0; tt[q] = ton[q] ? idx - tch[q] * T : 0;
+    }
+    float2 pre[4];
+    auto fetch = [&](int f) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int chc = tch[q] < nSH ? tch[q] : nSH - 1;
+            pre[q] = X[(long long)chc * l.x_ch + f * T + tt[q]];
+        }
+    };
+    fetch(0);
     for (int f = 0; f < l.nFrames; f++) {
         __syncthreads();
-        for (int idx = tid; idx < 64 * T; idx += 256) {
-            const int ch = idx / T, t = idx - ch * T;
-            s_x[ch][t] = ch < nSH ? X[(long long)ch * l.x_ch + f * T + t] : make_float2(0.f, 0.f);
-        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (ton[q]) s_x[tch[q]][tt[q]] = tch[q] < nSH ? pre[q] : make_float2(0.f, 0.f);
         __syncthreads();
+        fetch(f + 1 < l.nFrames ? f + 1 : f);
         float2 n[4][4];
 #pragma unroll
         for (int u = 0; u < 4; u++)
@@ -83,39 +101,61 @@ void launch_cov_update(const CovLaunch& l)
 
 struct PwdArgs { PwdLaunch l; };
 
+/* grid (64 rows); 256 threads = 64 columns x 4 band groups.  Every load is unconditional (a load under a branch gets its
+ * own wait: the first version made 133 dependent round trips, 60 us); a band's contribution is masked by a select.  Each
+ * group sums its contiguous band range in ascending order and the four partial sums are added in group order. */
 __global__ __launch_bounds__(256) void cgrp_kernel(PwdArgs a)
 {
+    __shared__ float s_p[4][64];
     const PwdLaunch& l = a.l;
-    const int e = blockIdx.x * 256 + threadIdx.x;          /* all 64 x 64 entries: outside the nM x nM block the sum is empty */
-    const int i = e >> 6, j = e & 63;
+    const int i = blockIdx.x, j = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int per = (l.nBands + 3) / 4;
+    const int b0 = g * per, b1 = b0 + per < l.nBands ? b0 + per : l.nBands;
     float acc = 0.0f;
-    for (int band = 0; band < l.nBands; band++) {
+    const float2* Ce = l.Cx + i * 64 + j;
+#pragma unroll 17
+    for (int band = b0; band < b1; band++) {
         const int ns = l.bandNSH[band];
-        if (i < ns && j < ns) acc += l.Cx[(long long)band * 64 * 64 + i * 64 + j].x * l.bandScale[band];   /* crmulf then ccaddf (powermap.c:288) */
+        const float v = Ce[(long long)band * 64 * 64].x * l.bandScale[band];      /* crmulf then ccaddf (powermap.c:288) */
+        acc += (i < ns && j < ns) ? v : 0.0f;
     }
-    l.Cg[i * 64 + j] = acc;
+    s_p[g][j] = acc;
+    __syncthreads();
+    if (g == 0) l.Cg[i * 64 + j] = ((s_p[0][j] + s_p[1][j]) + s_p[2][j]) + s_p[3][j];
 }
 
+/* 256 threads = 64 directions x 4 row groups: thread (d, g) forms sum_{i in 16 g .. 16 g + 15} y_i (C y)_i; the four
+ * partial sums meet through LDS in group order. */
 __global__ __launch_bounds__(256) void pwd_kernel(PwdArgs a)
 {
     __shared__ float s_C[64 * 64];
+    __shared__ float s_part[4][64];
     const PwdLaunch& l = a.l;
     for (int e = threadIdx.x; e < 64 * 64; e += 256) s_C[e] = l.Cg[e];
-    __syncthreads();
-    const int d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= l.G) return;
+    const int dl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + dl;
+    const int dc = d < l.G ? d : l.G - 1;
     float y[64];
 #pragma unroll
-    for (int i = 0; i < 64; i++) y[i] = i < l.nM ? l.Ygrid[(long long)i * l.G + d] : 0.0f;
+    for (int i = 0; i < 64; i++) { const float v = l.Ygrid[(long long)(i < l.nM ? i : 0) * l.G + dc]; y[i] = i < l.nM ? v : 0.0f; }
+    float yrow[16];                                        /* y_i of this thread's rows (y[] is indexed statically only) */
+#pragma unroll
+    for (int ii = 0; ii < 16; ii++) { const int i = g * 16 + ii; const float v = l.Ygrid[(long long)(i < l.nM ? i : 0) * l.G + dc]; yrow[ii] = i < l.nM ? v : 0.0f; }
+    __syncthreads();
     float acc = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 64; i++) {                         /* rows/columns beyond nM are zero on both sides */
+    for (int ii = 0; ii < 16; ii++) {                      /* rows/columns beyond nM are zero on both sides */
+        const int i = g * 16 + ii;
         float cy = 0.0f;
 #pragma unroll
         for (int j = 0; j < 64; j++) cy = fmaf(s_C[i * 64 + j], y[j], cy);
-        acc = fmaf(y[i], cy, acc);
+        acc = fmaf(yrow[ii], cy, acc);
     }
-    const float v = (1.0f - l.avg) * acc + l.avg * l.prev_pmap[d];
+    s_part[g][dl] = acc;
+    __syncthreads();
+    if (g != 0 || d >= l.G) return;
+    const float tot = ((s_part[0][dl] + s_part[1][dl]) + s_part[2][dl]) + s_part[3][dl];
+    const float v = (1.0f - l.avg) * tot + l.avg * l.prev_pmap[d];
     l.pmap[d] = v;
     l.prev_pmap[d] = v;
 }
@@ -124,8 +164,8 @@ void launch_pwd_map(const PwdLaunch& l)
 {
     PwdArgs a; a.l = l;
     KernelTimer kt("pwd_map");
-    hipLaunchKernelGGL(cgrp_kernel, dim3(16), dim3(256), 0, stream(), a);
-    hipLaunchKernelGGL(pwd_kernel, dim3((l.G + 255) / 256), dim3(256), 0, stream(), a);
+    hipLaunchKernelGGL(cgrp_kernel, dim3(64), dim3(256), 0, stream(), a);
+    hipLaunchKernelGGL(pwd_kernel, dim3((l.G + 63) / 64), dim3(256), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 
