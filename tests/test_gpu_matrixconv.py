@@ -32,7 +32,7 @@ def run(mc, x, hop):
 
 
 @pytest.mark.parametrize("part", [1, 0])
-@pytest.mark.parametrize("hop,L,nIn,nOut", [(64, 96, 3, 2), (128, 128, 4, 3), (96, 100, 2, 2), (256, 1000, 5, 2), (32, 7, 1, 1), (4096, 5000, 2, 3), (4, 9, 2, 1)])
+@pytest.mark.parametrize("hop,L,nIn,nOut", [(64, 96, 3, 2), (128, 128, 4, 3), (96, 100, 2, 2), (256, 1000, 5, 2), (32, 7, 1, 1), (4096, 5000, 2, 3), (4, 9, 2, 1), (64, 96, 40, 2), (128, 300, 64, 3)])
 def test_matrixconv_vs_oracle_and_direct(saf, orc, part, hop, L, nIn, nOut):
     H = (np.random.default_rng(hop + L).normal(size=(nOut, nIn, L)) / 8).astype(np.float32)
     x = frames(hop * 3 + L, nIn, 9 * hop)
