@@ -161,6 +161,15 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
     const unsigned offHist = (unsigned)(fchc * (SAF_ANA_HIST * SAF_HOP) + fn);
     const float* inBase = g.a.in + (long long)inst * g.a.in_inst;
     const float* histBase = g.a.hist_rd + (long long)inst * g.a.nCh * (SAF_ANA_HIST * SAF_HOP);
+    /* uniform 64-bit base + 32-bit BYTE offset per lane (launch_analysis checks the extents): with a float index the
+     * compiler must assume that 4 * index overflows 32 bits and does a 64-bit vector add per load */
+    const unsigned offInB = offIn * 4u;
+    auto ld_in = [&](const float* base) {
+        /* `base` is uniform: pin it to scalar registers so that the access is  s[base] + v(32-bit offset) */
+        const unsigned long long b = (unsigned long long)base;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo) + offInB);
+    };
     float w[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) w[k] = g.win[k * SAF_HOP + fn];
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
     }
 #pragma unroll
     for (int i = 0; i < SUB; i++) {
-        xin[9 + i] = (inBase + curOff)[offIn] * scale;
+        xin[9 + i] = ld_in(inBase + curOff) * scale;
         if (c0 + i + 1 < c1) { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += g.a.in_frame - (long long)T * SAF_HOP; } }
     }
     /* hop h of this chunk lives in ring position (h - (c0 - 6)) % ARING */
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
         if (more) {
 #pragma unroll
             for (int i = 0; i < SUB; i++) {
-                xl[i] = (inBase + curOff)[offIn];
+                xl[i] = ld_in(inBase + curOff);
                 if (s0 + SUB + i + 1 < c1) { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += g.a.in_frame - (long long)T * SAF_HOP; } }
             }
         }
@@ -271,42 +280,56 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
             int pD = pos - 3; if (pD < 0) pD += ARING;                         /* all bands are delayed 3 hops */
             if (!g.a.hybrid) pD = pos;                                         /* plain STFT bins, no hybrid delay */
             const unsigned ohop = (unsigned)(s0 + st);
-            for (int ii = 0; ii < 9; ii++) {
-                const int item = sr + 8 * NCH * ii;
-                if (item >= 65 * nC) break;
-                const int c = item >= 65 ? 1 : 0;
-                const int k = item - 65 * c;
+            /* one item = bins k and 128-k of (channel c, this hop).  FIRST: k < 8, the only items that can hold the hybrid
+             * bins 1..4; LAST: k = 64, whose partner is itself.  The item loop is fully unrolled with these cases resolved
+             * at compile time: the kernel is instruction-issue bound, and the rolled loop with its exit test and per-item
+             * case analysis cost 9 % of its time. */
+            static_assert(NCH == 1, "the item schedule below assumes 8 item lanes per channel (128 threads)");
+            /* spectra stores: uniform 64-bit base + 32-bit byte offset per lane (launch_analysis checks that an instance's
+             * spectra span less than 4 GiB): no 64-bit address arithmetic per store */
+            char* const ob = reinterpret_cast<char*>(outBase);
+            auto put = [&](unsigned idx, float2 v) { *reinterpret_cast<float2*>(ob + (idx << 3)) = v; };
+            auto item = [&](int k, int c, bool FIRST, bool LAST) {
                 const float* ring = s_ring + c * ARING * SLOT;
                 const float2 W = s_tw256[k];
                 float2 Xk, Xm;
                 ana_bin_pair(ring + pD * SLOT, SLOT_SG(pD), k, W, Xk, Xm);
                 const unsigned o = (unsigned)c * oc32 + ohop;
                 if (!g.a.hybrid) {
-                    outBase[(unsigned)k * ob32 + o] = Xk;
-                    if (k != 64) outBase[(unsigned)(128 - k) * ob32 + o] = Xm;
+                    put((unsigned)k * ob32 + o, Xk);
+                    if (!LAST) put((unsigned)(128 - k) * ob32 + o, Xm);
+                    return;
+                }
+                if (!LAST) put((unsigned)(132 - k) * ob32 + o, Xm);                /* bins 5..128 -> bands 9..132 */
+                if (!FIRST || k == 0 || k >= 5) {
+                    put((unsigned)(k == 0 ? 0 : k + 4) * ob32 + o, Xk);
                 } else {
-                    if (k != 64) outBase[(unsigned)(132 - k) * ob32 + o] = Xm;         /* bins 5..128 -> bands 9..132 */
-                    if (k == 0 || k >= 5) {
-                        outBase[(unsigned)(k == 0 ? 0 : k + 4) * ob32 + o] = Xk;
-                    } else {
-                        int p2 = pos - 2; if (p2 < 0) p2 += ARING;
-                        int p4 = pos - 4; if (p4 < 0) p4 += ARING;
-                        int p6 = pos - 6; if (p6 < 0) p6 += ARING;
-                        const float2 S0 = ana_bin_lo(ring + pos * SLOT, SLOT_SG(pos), k, W);
-                        const float2 S2 = ana_bin_lo(ring + p2 * SLOT, SLOT_SG(p2), k, W);
-                        const float2 S4 = ana_bin_lo(ring + p4 * SLOT, SLOT_SG(p4), k, W);
-                        const float2 S6 = ana_bin_lo(ring + p6 * SLOT, SLOT_SG(p6), k, W);
-                        float gr, gi;
-                        gr = -COEFF1 * S0.y;          gi = COEFF1 * S0.x;
-                        gr -= COEFF2 * S2.y;          gi += COEFF2 * S2.x;
-                        gr += COEFF2 * S4.y;          gi -= COEFF2 * S4.x;
-                        gr += COEFF1 * S6.y;          gi -= COEFF1 * S6.x;
-                        const float dr = Xk.x * 0.5f, di = Xk.y * 0.5f;
-                        /* lower half-band (band 2k-1) of bins 1,3 subtracts, of bins 2,4 adds (afSTFT_internal.c:606-619) */
-                        const float sgn = (k & 1) ? -1.0f : 1.0f;
-                        outBase[(unsigned)(2 * k - 1) * ob32 + o] = make_float2(dr + sgn * gr, di + sgn * gi);
-                        outBase[(unsigned)(2 * k) * ob32 + o] = make_float2(dr - sgn * gr, di - sgn * gi);
-                    }
+                    int p2 = pos - 2; if (p2 < 0) p2 += ARING;
+                    int p4 = pos - 4; if (p4 < 0) p4 += ARING;
+                    int p6 = pos - 6; if (p6 < 0) p6 += ARING;
+                    const float2 S0 = ana_bin_lo(ring + pos * SLOT, SLOT_SG(pos), k, W);
+                    const float2 S2 = ana_bin_lo(ring + p2 * SLOT, SLOT_SG(p2), k, W);
+                    const float2 S4 = ana_bin_lo(ring + p4 * SLOT, SLOT_SG(p4), k, W);
+                    const float2 S6 = ana_bin_lo(ring + p6 * SLOT, SLOT_SG(p6), k, W);
+                    float gr, gi;
+                    gr = -COEFF1 * S0.y;          gi = COEFF1 * S0.x;
+                    gr -= COEFF2 * S2.y;          gi += COEFF2 * S2.x;
+                    gr += COEFF2 * S4.y;          gi -= COEFF2 * S4.x;
+                    gr += COEFF1 * S6.y;          gi -= COEFF1 * S6.x;
+                    const float dr = Xk.x * 0.5f, di = Xk.y * 0.5f;
+                    /* lower half-band (band 2k-1) of bins 1,3 subtracts, of bins 2,4 adds (afSTFT_internal.c:606-619) */
+                    const float sgn = (k & 1) ? -1.0f : 1.0f;
+                    put((unsigned)(2 * k - 1) * ob32 + o, make_float2(dr + sgn * gr, di + sgn * gi));
+                    put((unsigned)(2 * k) * ob32 + o, make_float2(dr - sgn * gr, di - sgn * gi));
+                }
+            };
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if (c < nC) {
+                    item(sr, c, true, false);
+#pragma unroll
+                    for (int ii = 1; ii < 8; ii++) item(sr + 8 * ii, c, false, false);
+                    if (sr == 0) item(64, c, false, true);
                 }
             }
         }
@@ -376,7 +399,10 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
         const float2* twJ = s_twJ + fj * 16;
         const float2* inBase = g.s.in + (long long)inst * g.s.in_inst + (long long)ch * g.s.in_ch;
         const unsigned ib32 = (unsigned)g.s.in_band;
-        const int gt = tid & 15, gq = tid >> 4;                   /* gather role: hop of the sub-chunk, item lane (8) */
+        /* spectra loads: uniform 64-bit base + 32-bit byte offset per lane (launch_synthesis checks the extent) */
+        const char* const ibc = reinterpret_cast<const char*>(inBase);
+        auto get = [&](unsigned idx) { return *reinterpret_cast<const float2*>(ibc + (idx << 3)); };
+        const int gt = tid & 15, gq = (tid >> 4) & 7;             /* gather role: hop of the sub-chunk, item lane (8); the mask tells the compiler the range, so the per-item case analysis folds after unrolling */
         for (int it = -1; it <= nSub; it++) {
             const int s0 = hs + it * SUB;
             if (it >= 0 && it < nSub) {
@@ -392,11 +418,11 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
                     int bk, bm;
                     if (!g.s.hybrid) { bk = k; bm = 128 - k; }
                     else { bm = 132 - k; bk = k == 0 ? 0 : (k < 5 ? 2 * k - 1 : k + 4); }      /* bin k = band 2k-1 (+ band 2k), k = 1..4 */
-                    rXk[i] = inBase[(unsigned)bk * ib32 + ohop];
-                    rXm[i] = inBase[(unsigned)bm * ib32 + ohop];
+                    rXk[i] = get((unsigned)bk * ib32 + ohop);
+                    rXm[i] = get((unsigned)bm * ib32 + ohop);
                     if (i == 0) {                   /* the only pass that can hold bins 1..4 */
                         const bool pair = g.s.hybrid && k >= 1 && k < 5;
-                        const float2 u = inBase[(unsigned)(pair ? 2 * k : bk) * ib32 + ohop];
+                        const float2 u = get((unsigned)(pair ? 2 * k : bk) * ib32 + ohop);
                         rX2 = pair ? u : make_float2(0.f, 0.f);
                     }
                 }
@@ -674,6 +700,10 @@ void launch_analysis(const AnaLaunch& a)
         }
     }
     g.chunk = chunk;
+    /* the kernel addresses one instance's samples and spectra with 32-bit byte offsets from uniform bases */
+    if ((unsigned long long)(a.nChIn > 0 ? a.nChIn : 1) * (unsigned long long)(a.in_ch < 0 ? -a.in_ch : a.in_ch) * 4ull >= (1ull << 32) ||
+        ((unsigned long long)SAF_NBANDS * (unsigned long long)a.out_band + (unsigned long long)a.nCh * (unsigned long long)a.out_ch + (unsigned long long)a.H) * 8ull >= (1ull << 32))
+        SAF_FATAL("afSTFT analysis: one instance's channel block or spectra exceed 4 GiB (split the call)");
     dim3 grid((a.H + g.chunk - 1) / g.chunk, (a.nCh + NCHW - 1) / NCHW, a.nInst);
     KernelTimer kt("afstft_analysis");
     hipLaunchKernelGGL(afstft_analysis_kernel<NCHW>, grid, dim3(128 * NCHW), 0, stream(), g);
@@ -697,6 +727,8 @@ void launch_synthesis(const SynLaunch& s)
         if (nChunks > s.H / 64) nChunks = s.H / 64;
         if (nChunks > 1) g.chunk = ((s.H + nChunks - 1) / nChunks + SUB - 1) / SUB * SUB;
     }
+    if (((unsigned long long)SAF_NBANDS * (unsigned long long)s.in_band + (unsigned long long)s.H) * 8ull >= (1ull << 32))
+        SAF_FATAL("afSTFT synthesis: one channel's spectra span more than 4 GiB (split the call)");
     dim3 grid(s.nCh, s.nInst, (s.H + g.chunk - 1) / g.chunk);
     KernelTimer kt("afstft_synthesis");
     hipLaunchKernelGGL(afstft_synthesis_ws_kernel, grid, dim3(256), 0, stream(), g);
