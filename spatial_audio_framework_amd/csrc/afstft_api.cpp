@@ -108,8 +108,11 @@ static void forward_host(AfSTFT* h, int framesize, Rd rd)
     const int nHops = framesize / h->hop, nCH = h->st.nCHin;
     h->ensure((size_t)(nCH > h->st.nCHout ? nCH : h->st.nCHout) * framesize, (size_t)h->nBands * (nCH > h->st.nCHout ? nCH : h->st.nCHout) * nHops);
     for (int ch = 0; ch < nCH; ch++) memcpy(h->h_td.p + (size_t)ch * framesize, rd(ch), sizeof(float) * framesize);
-    HIP_CHECK(hipMemcpyAsync(h->d_td.p, h->h_td.p, sizeof(float) * (size_t)nCH * framesize, hipMemcpyHostToDevice, stream()));
-    run_forward(h, h->d_td.p, framesize, nHops, h->d_fd.p, (long long)nCH * nHops, nHops);
+    if (zero_copy_io()) run_forward(h, h->h_td.p, framesize, nHops, h->d_fd.p, (long long)nCH * nHops, nHops);       /* the kernel reads the pinned samples directly */
+    else {
+        HIP_CHECK(hipMemcpyAsync(h->d_td.p, h->h_td.p, sizeof(float) * (size_t)nCH * framesize, hipMemcpyHostToDevice, stream()));
+        run_forward(h, h->d_td.p, framesize, nHops, h->d_fd.p, (long long)nCH * nHops, nHops);
+    }
     HIP_CHECK(hipMemcpyAsync(h->h_fd.p, h->d_fd.p, sizeof(float2) * (size_t)h->nBands * nCH * nHops, hipMemcpyDeviceToHost, stream()));
     HIP_CHECK(hipStreamSynchronize(stream()));
 }
@@ -119,8 +122,11 @@ static void backward_host(AfSTFT* h, int framesize)
 {
     const int nHops = framesize / h->hop, nCH = h->st.nCHout;
     HIP_CHECK(hipMemcpyAsync(h->d_fd.p, h->h_fd.p, sizeof(float2) * (size_t)h->nBands * nCH * nHops, hipMemcpyHostToDevice, stream()));
-    run_backward(h, h->d_fd.p, (long long)nCH * nHops, nHops, nHops, h->d_td.p, framesize);
-    HIP_CHECK(hipMemcpyAsync(h->h_td.p, h->d_td.p, sizeof(float) * (size_t)nCH * framesize, hipMemcpyDeviceToHost, stream()));
+    if (zero_copy_io()) run_backward(h, h->d_fd.p, (long long)nCH * nHops, nHops, nHops, h->h_td.p, framesize);      /* the kernel writes the pinned samples directly */
+    else {
+        run_backward(h, h->d_fd.p, (long long)nCH * nHops, nHops, nHops, h->d_td.p, framesize);
+        HIP_CHECK(hipMemcpyAsync(h->h_td.p, h->d_td.p, sizeof(float) * (size_t)nCH * framesize, hipMemcpyDeviceToHost, stream()));
+    }
     HIP_CHECK(hipStreamSynchronize(stream()));
 }
 
