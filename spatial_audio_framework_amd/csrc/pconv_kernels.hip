@@ -43,14 +43,18 @@ __device__ __forceinline__ float2 pc_tw(const float2* s_tw, int k, int halfM)
 /* M-point complex FFT of the sequence whose elements tid + q*M/8 this thread holds in v[q]; the result is left in
  * natural order in s (padded: element i at PC_PAD(i)).  nthr = M/8 threads take part (tid < nthr); all threads of the
  * workgroup must call (barriers).  s_tw: half-circle twiddles in LDS.  INV: conjugated twiddles, unscaled. */
-template <bool INV>
-__device__ __forceinline__ void pc_fft(float2 (&v)[8], float2* s, const float2* s_tw, int M, int logM, int tid)
+/* LOGM > 0: transform size known at compile time (passes unrolled, strides and twiddle steps constant); LOGM = 0: the
+ * runtime M / logM are used. */
+template <bool INV, int LOGM>
+__device__ __forceinline__ void pc_fft(float2 (&v)[8], float2* s, const float2* s_tw, int M_rt, int logM_rt, int tid)
 {
+    const int logM = LOGM > 0 ? LOGM : logM_rt;
+    const int M = LOGM > 0 ? (1 << LOGM) : M_rt;
     const int M8 = M >> 3, halfM = M >> 1;
     const bool on = tid < M8;
-    int Ns = 1, rem = logM;
+    int Ns = 1;
     /* first pass: radix 2 or 4 when log2 M is not a multiple of 3 (no twiddles at Ns = 1) */
-    const int r0 = rem % 3;
+    const int r0 = logM % 3;
     if (r0 == 1) {
         /* 4 radix-2 butterflies: jj = tid + u*M8, inputs v[u], v[u + 4]; outputs at 2*jj, 2*jj + 1 */
 #pragma unroll
@@ -60,7 +64,7 @@ __device__ __forceinline__ void pc_fft(float2 (&v)[8], float2* s, const float2* 
 #pragma unroll
             for (int u = 0; u < 4; u++) { const int o = 2 * (tid + u * M8); s[PC_PAD(o)] = v[u]; s[PC_PAD(o + 1)] = v[u + 4]; }
         }
-        Ns = 2; rem -= 1;
+        Ns = 2;
     } else if (r0 == 2) {
         /* 2 radix-4 butterflies: jj = tid + u*M8, inputs v[u + 2r]; outputs at 4*jj + r */
 #pragma unroll
@@ -74,7 +78,7 @@ __device__ __forceinline__ void pc_fft(float2 (&v)[8], float2* s, const float2* 
                 for (int r = 0; r < 4; r++) s[PC_PAD(o + r)] = v[u + 2 * r];
             }
         }
-        Ns = 4; rem -= 2;
+        Ns = 4;
     }
     if (r0 != 0) {
         __syncthreads();
@@ -83,10 +87,10 @@ __device__ __forceinline__ void pc_fft(float2 (&v)[8], float2* s, const float2* 
             for (int q = 0; q < 8; q++) v[q] = s[PC_PAD(tid + q * M8)];
         }
     }
-    while (rem > 0) {
-        const int jm = tid & (Ns - 1);
-        if (Ns > 1) {
-            const int step = jm * (M / (8 * Ns));                 /* exponent of the r = 1 twiddle in units of 1/M turns */
+    auto pass = [&](int Ns_, bool last) {
+        const int jm = tid & (Ns_ - 1);
+        if (Ns_ > 1) {
+            const int step = jm * (M / (8 * Ns_));               /* exponent of the r = 1 twiddle in units of 1/M turns */
 #pragma unroll
             for (int r = 1; r < 8; r++) { float2 w = pc_tw(s_tw, r * step, halfM); if (INV) w.y = -w.y; v[r] = cmul(v[r], w); }
         }
@@ -95,14 +99,19 @@ __device__ __forceinline__ void pc_fft(float2 (&v)[8], float2* s, const float2* 
         if (on) {
             const int base = ((tid - jm) << 3) + jm;
 #pragma unroll
-            for (int r = 0; r < 8; r++) s[PC_PAD(base + r * Ns)] = X8(v, r);
+            for (int r = 0; r < 8; r++) s[PC_PAD(base + r * Ns_)] = X8(v, r);
         }
-        Ns <<= 3; rem -= 3;
         __syncthreads();
-        if (rem > 0 && on) {
+        if (!last && on) {
 #pragma unroll
             for (int q = 0; q < 8; q++) v[q] = s[PC_PAD(tid + q * M8)];
         }
+    };
+    if (LOGM > 0) {
+#pragma unroll
+        for (int p = 0; p < LOGM / 3; p++) pass(((LOGM % 3) == 0 ? 1 : ((LOGM % 3) == 1 ? 2 : 4)) << (3 * p), p == LOGM / 3 - 1);
+    } else {
+        for (int rem = logM - r0; rem > 0; rem -= 3) { pass(Ns, rem == 3); Ns <<= 3; }
     }
 }
 
@@ -120,10 +129,11 @@ struct FwdArgs {
 /* grid (ceil(g0 / fpw), g1, g2); fpw transforms per workgroup, max(64, M/8) threads each (one-wave workgroups are
  * bound by the workgroup dispatch rate: 4096 of them took 19 us whatever they did).
  * dynamic LDS: fpw x (M + M/8) data + M/2 twiddles, float2 each */
+template <int LOGM>
 __global__ __launch_bounds__(1024) void pconv_rfft_fwd_kernel(FwdArgs a)
 {
     extern __shared__ float2 s_pc[];
-    const int M = a.M, logM = a.logM, M8 = M >> 3;
+    const int M = LOGM > 0 ? (1 << LOGM) : a.M, logM = LOGM > 0 ? LOGM : a.logM, M8 = M >> 3;
     const int tpf = (int)blockDim.x / a.fpw;                       /* threads per transform */
     const int sub = threadIdx.x / tpf, tid = threadIdx.x - sub * tpf;
     const int fx = blockIdx.x * a.fpw + sub;
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(1024) void pconv_rfft_fwd_kernel(FwdArgs a)
     for (int i = 0; i < 8; i++) wk[i] = a.tw[tc + i * M8];
     for (int k = threadIdx.x; k < (M >> 1); k += blockDim.x) s_tw[k] = a.tw[2 * k];
     __syncthreads();
-    pc_fft<false>(v, s, s_tw, M, logM, tid < M8 ? tid : M8);             /* tid >= M/8: takes part in the barriers only */
+    pc_fft<false, LOGM>(v, s, s_tw, M, logM, tid < M8 ? tid : M8);             /* tid >= M/8: takes part in the barriers only */
     if (!on) return;
     const int y = a.ringLen ? (a.ringHead + (int)blockIdx.y) % a.ringLen : (int)blockIdx.y;
     float2* dst = a.dst + (long long)fx * a.d0 + (long long)y * a.d1 + (long long)blockIdx.z * a.d2;
@@ -278,10 +288,11 @@ struct InvArgs {
  * threads: group g = tid / (M/8) takes the splits g, g + G, ...; the groups meet in LDS), rebuilds the packed
  * half-size spectrum, inverse FFT, scale 1/M (= the 1/N of the real transform times the 2 of the packing).
  * dynamic LDS: (M + M/8) data + M/2 twiddles + G*M fold, float2 each. */
+template <int LOGM>
 __global__ __launch_bounds__(1024) void pconv_irfft_kernel(InvArgs a)
 {
     extern __shared__ float2 s_pc[];
-    const int M = a.M, logM = a.logM, M8 = M >> 3, tid = threadIdx.x, o = blockIdx.x, t = blockIdx.y;
+    const int M = LOGM > 0 ? (1 << LOGM) : a.M, logM = LOGM > 0 ? LOGM : a.logM, M8 = M >> 3, tid = threadIdx.x, o = blockIdx.x, t = blockIdx.y;
     float2* s = s_pc;
     float2* s_tw = s_pc + M + M8;
     float2* s_fold = s_tw + (M >> 1);
@@ -330,7 +341,7 @@ __global__ __launch_bounds__(1024) void pconv_irfft_kernel(InvArgs a)
         if (k == 0) Z[i] = make_float2(0.5f * (Xk.x + Xk.y), 0.5f * (Xk.x - Xk.y));     /* packed (Re X[0], Re X[M]) */
     }
     /* Z[i] is element tid + i*M/8 of the half-size spectrum: exactly the registers the FFT starts from */
-    pc_fft<true>(Z, s, s_tw, M, logM, tid);
+    pc_fft<true, LOGM>(Z, s, s_tw, M, logM, tid);
     if (!on) return;
     const int slot = (a.zHead + t) % a.zRing;
     float2* z = reinterpret_cast<float2*>(a.zs + ((long long)slot * a.nOut + o) * (2 * M));
@@ -452,14 +463,28 @@ static int fft_threads(int M) { return M / 8 < 64 ? 64 : M / 8; }
 static size_t fft_lds(int M) { return sizeof(float2) * (size_t)(M + M / 8 + M / 2); }
 static int inv_threads(int M, int kSplit) { return (kSplit > 1 && M / 8 < 256) ? 256 : fft_threads(M); }
 static size_t inv_lds(int M, int kSplit) { const int G = inv_threads(M, kSplit) / (M / 8); return fft_lds(M) + (G > 1 ? sizeof(float2) * (size_t)(G - 1) * M : 0); }
+/* the common transform sizes (hop 64 .. 4096) get kernels specialised on log2 M */
+#define PC_DISPATCH(LOGM_RT, CALL)                                                  \
+    switch (LOGM_RT) {                                                              \
+        case 6: { constexpr int L = 6; CALL; } break;                               \
+        case 7: { constexpr int L = 7; CALL; } break;                               \
+        case 8: { constexpr int L = 8; CALL; } break;                               \
+        case 9: { constexpr int L = 9; CALL; } break;                               \
+        case 10: { constexpr int L = 10; CALL; } break;                             \
+        case 11: { constexpr int L = 11; CALL; } break;                             \
+        case 12: { constexpr int L = 12; CALL; } break;                             \
+        default: { constexpr int L = 0; CALL; } break;                              \
+    }
+
 static void fft_check(int N)
 {
     const int M = N / 2, logM = ilog2(M);
     if ((1 << logM) != M || M < 8 || M > 8192) SAF_FATAL("matrixConv: FFT size %d unsupported (16 .. 16384; use the partitioned mode for long filters)", N);
+    /* only M = 8192 (the runtime-size instantiation) needs more than the default 64 KiB of dynamic LDS */
     static bool raised = false;
-    if (!raised) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)pconv_rfft_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(8192)));
-        HIP_CHECK(hipFuncSetAttribute((const void*)pconv_irfft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(8192)));
+    if (M > 4096 && !raised) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)pconv_rfft_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(8192)));
+        HIP_CHECK(hipFuncSetAttribute((const void*)pconv_irfft_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(8192)));
         raised = true;
     }
 }
@@ -477,7 +502,7 @@ void pconv_launch_fwd(const PconvFwd& f)
     a.g0 = f.g0; a.fpw = fpw;
     const size_t lds = sizeof(float2) * (size_t)(a.M / 2 + fpw * (a.M + a.M / 8));
     KernelTimer kt("pconv_fft");
-    hipLaunchKernelGGL(pconv_rfft_fwd_kernel, dim3((f.g0 + fpw - 1) / fpw, f.g1, f.g2), dim3(tpf * fpw), lds, stream(), a);
+    PC_DISPATCH(a.logM, hipLaunchKernelGGL(pconv_rfft_fwd_kernel<L>, dim3((f.g0 + fpw - 1) / fpw, f.g1, f.g2), dim3(tpf * fpw), lds, stream(), a));
     HIP_CHECK(hipGetLastError());
 }
 
@@ -513,7 +538,7 @@ void pconv_launch_apply(const PconvApply& p)
         a.P = p.P; a.zs = p.zs; a.tw = p.tw; a.nOut = p.nOut; a.kSplit = kSplit; a.M = M; a.logM = logM;
         a.zRing = p.zRing; a.zHead = p.zHead;
         KernelTimer kt("pconv_ifft");
-        hipLaunchKernelGGL(pconv_irfft_kernel, dim3(p.nOut, p.T), dim3(inv_threads(M, kSplit)), inv_lds(M, kSplit), stream(), a);
+        PC_DISPATCH(logM, hipLaunchKernelGGL(pconv_irfft_kernel<L>, dim3(p.nOut, p.T), dim3(inv_threads(M, kSplit)), inv_lds(M, kSplit), stream(), a));
         HIP_CHECK(hipGetLastError());
     }
     {
@@ -542,7 +567,7 @@ void tvconv_launch_apply(const TvApply& p)
         a.P = p.P; a.zs = p.zs; a.tw = p.tw; a.nOut = p.nOut * 3; a.kSplit = 1; a.M = M; a.logM = logM;
         a.zRing = p.zRing; a.zHead = p.zHead;
         KernelTimer kt("pconv_ifft");
-        hipLaunchKernelGGL(pconv_irfft_kernel, dim3(p.nOut * 3, p.T), dim3(fft_threads(M)), fft_lds(M), stream(), a);
+        PC_DISPATCH(logM, hipLaunchKernelGGL(pconv_irfft_kernel<L>, dim3(p.nOut * 3, p.T), dim3(fft_threads(M)), fft_lds(M), stream(), a));
         HIP_CHECK(hipGetLastError());
     }
     {
