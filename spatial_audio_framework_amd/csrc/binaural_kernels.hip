@@ -80,16 +80,19 @@ __global__ __launch_bounds__(256) void binaural_mac_kernel(MacArgs2 a)
     const int t = tid & (a.TT - 1), sg = tid >> a.logTT, nG = 256 >> a.logTT;
     const int hop = blockIdx.x * a.TT + t;
     float2 accL = make_float2(0.f, 0.f), accR = make_float2(0.f, 0.f);
-    if (hop < l.H) {
-        const float2* X = l.X + (long long)blockIdx.z * l.x_inst + (long long)band * l.x_band + hop;
-        const float2* hh = l.h + (long long)blockIdx.z * l.h_inst;
+    {
+        /* unconditional loads (hops beyond H re-read the last one and are never stored), 4 sources in flight per thread */
+        const int hopc = hop < l.H ? hop : l.H - 1;
+        const float2* X = l.X + (long long)blockIdx.z * l.x_inst + (long long)band * l.x_band + hopc;
+        const float2* hh = l.h + (long long)blockIdx.z * l.h_inst + (long long)band * 2;
+#pragma unroll 4
         for (int src = sg; src < l.nSrc; src += nG) {
             const float2 x = X[(long long)src * l.x_ch];
-            const float2 hl = hh[((long long)src * SAF_NBANDS + band) * 2], hr = hh[((long long)src * SAF_NBANDS + band) * 2 + 1];
-            accL.x = fmaf(hl.x, x.x, accL.x); accL.x = fmaf(-hl.y, x.y, accL.x);
-            accL.y = fmaf(hl.x, x.y, accL.y); accL.y = fmaf(hl.y, x.x, accL.y);
-            accR.x = fmaf(hr.x, x.x, accR.x); accR.x = fmaf(-hr.y, x.y, accR.x);
-            accR.y = fmaf(hr.x, x.y, accR.y); accR.y = fmaf(hr.y, x.x, accR.y);
+            const float4 hv = *reinterpret_cast<const float4*>(hh + (long long)src * SAF_NBANDS * 2);     /* left, right */
+            accL.x = fmaf(hv.x, x.x, accL.x); accL.x = fmaf(-hv.y, x.y, accL.x);
+            accL.y = fmaf(hv.x, x.y, accL.y); accL.y = fmaf(hv.y, x.x, accL.y);
+            accR.x = fmaf(hv.z, x.x, accR.x); accR.x = fmaf(-hv.w, x.y, accR.x);
+            accR.y = fmaf(hv.z, x.y, accR.y); accR.y = fmaf(hv.w, x.x, accR.y);
         }
     }
     s_red[tid][0] = accL; s_red[tid][1] = accR;
