@@ -486,3 +486,31 @@ def test_vbap2d_and_spread_ring_vs_oracle(saf, orc):
     assert maxabs(saf.generateVBAPgainTable2D_srcs(az, ls)[0], orc.generateVBAPgainTable2D_srcs(az, ls)[0]) < 2e-6
     for a, e, sp, ns, nr in ((0.3, -0.2, 40.0, 8, 1), (2.0, 1.565, 90.0, 8, 1), (-1.0, 0.4, 30.0, 6, 2)):
         assert maxabs(saf.getSpreadSrcDirs3D(a, e, sp, ns, nr), orc.getSpreadSrcDirs3D(a, e, sp, ns, nr)) < 2e-6
+
+
+def test_host_pointer_calls_staged_copies_equal_zero_copy(saf, orc):
+    """The one-block host-pointer entry points run their kernels on the pinned staging blocks (default) or copy them
+    through device memory (saf_hip_setZeroCopyIO(0)): both give the same samples, bit for bit."""
+    L = saf.load()
+    F, order = 256, 3
+    x = frames(21, 16, 10 * F)
+    H = (np.random.default_rng(4).normal(size=(2, 5, 300)) / 8).astype(np.float32)
+    xc = frames(22, 5, 8 * 128)
+    outs = []
+    for zc in (1, 0):
+        L.saf_hip_setZeroCopyIO(zc)
+        assert L.saf_hip_getZeroCopyIO() == zc
+        d = saf.AmbiDec(F)
+        d.setNormType(1); d.setChOrder(1); d.setMasterDecOrder(order); d.setOutputConfigPreset(21)
+        d.setDecMethod(0, 2); d.setDecMethod(1, 4); d.initCodec(); d.init(48000)
+        yd = np.concatenate([d.process(np.ascontiguousarray(x[:, i * F:(i + 1) * F]), 24) for i in range(10)], 1)
+        e = saf.AmbiEnc(F); e.init(48000); e.setOutputOrder(2); e.setNumSources(5)
+        ye = np.concatenate([e.process(np.ascontiguousarray(x[:5, i * F:(i + 1) * F]), 9) for i in range(4)], 1)
+        mc = saf.MatrixConv(128, H, 1)
+        yc = np.concatenate([mc.apply(np.ascontiguousarray(xc[:, i * 128:(i + 1) * 128])) for i in range(8)], 1)
+        a = saf.AfSTFT(4, 4)
+        ya = a.backward(a.forward(np.ascontiguousarray(x[:4, :2048])))
+        outs.append((yd, ye, yc, ya))
+    L.saf_hip_setZeroCopyIO(1)
+    for u, v in zip(*outs):
+        assert np.abs(u).max() > 1e-3 and np.array_equal(u, v)
