@@ -652,6 +652,60 @@ SAF_API void getBinauralAmbiDecoderMtx(float_complex* hrtfs, float* hrtf_dirs_de
 SAF_API void getBinauralAmbiDecoderFilters(float_complex* hrtfs, float* hrtf_dirs_deg, int N_dirs, int fftSize, float fs, BINAURAL_AMBI_DECODER_METHODS method, int order,
                                            float* itd_s, float* weights, int enableDiffCovMatching, int enableMaxReWeighting, float* decFilters);
 SAF_API void applyDiffCovMatching(float_complex* hrtfs, float* hrtf_dirs_deg, int N_dirs, int N_bands, int order, float* weights, float_complex* decMtx);   /* saf_hoa.c:502 */
+/* ------------------------------------------------------------------------------------------------------------
+ * rotator: rotation of an Ambisonic scene (examples/include/rotator.h:55-263; examples/src/rotator/rotator.c).
+ * Same block path as ambi_enc with the SH rotation matrix in place of the encoding matrix (one block of latency,
+ * linear cross-fade when the rotation changed).  The quaternion helpers are those of saf_utility_geometry.h:35-106.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct _quaternion_data { union { struct { float w, x, y, z; }; float Q[4]; }; } quaternion_data;       /* saf_utility_geometry.h:36-45 */
+typedef enum { EULER_ROTATION_Y_CONVENTION, EULER_ROTATION_X_CONVENTION, EULER_ROTATION_YAW_PITCH_ROLL, EULER_ROTATION_ROLL_PITCH_YAW } EULER_ROTATION_CONVENTIONS;   /* :48-54 */
+SAF_API void quaternion2rotationMatrix(quaternion_data* Q, float R[3][3]);                                        /* saf_utility_geometry.c:89 */
+SAF_API void rotationMatrix2quaternion(float R[3][3], quaternion_data* Q);                                        /* :107 */
+SAF_API void euler2Quaternion(float alpha, float beta, float gamma, int degreesFlag, EULER_ROTATION_CONVENTIONS convention, quaternion_data* Q);   /* :123 (the y- and x-conventions are unsupported there too) */
+SAF_API void quaternion2euler(quaternion_data* Q, int degreesFlag, EULER_ROTATION_CONVENTIONS convention, float* alpha, float* beta, float* gamma); /* :163 */
+/** Replaces -DROTATOR_FRAME_SIZE (default 64); call before rotator_create. */
+SAF_API void saf_hip_rotator_setFrameSize(int frameSize);
+SAF_API void rotator_create(void** const phRot);                                   /* rotator.h:61 */
+SAF_API void rotator_destroy(void** const phRot);                                  /* rotator.h:68 */
+SAF_API void rotator_init(void* const hRot, int samplerate);                       /* rotator.h:76 */
+SAF_API void rotator_process(void* const hRot, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples);   /* rotator.h:89 */
+/** nFrames consecutive blocks of device-resident ACN signals with the rotation set before the call (the cross-fade, if any, is on the first block). */
+SAF_API void saf_hip_rotator_process_dev(void* const hRot, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                         float* d_out, long long out_frame_stride, long long out_ch_stride, int nOutputs, int nFrames);
+SAF_API int  rotator_getFrameSize(void);                                           /* rotator.h:105 */
+SAF_API void rotator_setYaw(void* const hRot, float newYaw);                       /* rotator.h:108-171 */
+SAF_API void rotator_setPitch(void* const hRot, float newPitch);
+SAF_API void rotator_setRoll(void* const hRot, float newRoll);
+SAF_API void rotator_setQuaternionW(void* const hRot, float newValue);
+SAF_API void rotator_setQuaternionX(void* const hRot, float newValue);
+SAF_API void rotator_setQuaternionY(void* const hRot, float newValue);
+SAF_API void rotator_setQuaternionZ(void* const hRot, float newValue);
+SAF_API void rotator_setFlipYaw(void* const hRot, int newState);
+SAF_API void rotator_setFlipPitch(void* const hRot, int newState);
+SAF_API void rotator_setFlipRoll(void* const hRot, int newState);
+SAF_API void rotator_setFlipQuaternion(void* const hRot, int newState);
+SAF_API void rotator_setChOrder(void* const hRot, int newOrder);
+SAF_API void rotator_setNormType(void* const hRot, int newType);
+SAF_API void rotator_setOrder(void* const hRot, int newOrder);
+SAF_API void rotator_setRPYflag(void* const hRot, int newState);
+SAF_API float rotator_getYaw(void* const hRot);                                    /* rotator.h:179-256 */
+SAF_API float rotator_getPitch(void* const hRot);
+SAF_API float rotator_getRoll(void* const hRot);
+SAF_API float rotator_getQuaternionW(void* const hRot);
+SAF_API float rotator_getQuaternionX(void* const hRot);
+SAF_API float rotator_getQuaternionY(void* const hRot);
+SAF_API float rotator_getQuaternionZ(void* const hRot);
+SAF_API int  rotator_getFlipYaw(void* const hRot);
+SAF_API int  rotator_getFlipPitch(void* const hRot);
+SAF_API int  rotator_getFlipRoll(void* const hRot);
+SAF_API int  rotator_getFlipQuaternion(void* const hRot);
+SAF_API int  rotator_getRPYflag(void* const hRot);
+SAF_API int  rotator_getChOrder(void* const hRot);
+SAF_API int  rotator_getNormType(void* const hRot);
+SAF_API int  rotator_getOrder(void* const hRot);
+SAF_API int  rotator_getNSHrequired(void* const hRot);
+SAF_API int  rotator_getProcessingDelay(void);
+
 /** Replaces -DAMBI_BIN_FRAME_SIZE; call before ambi_bin_create. */
 SAF_API void saf_hip_ambi_bin_setFrameSize(int frameSize);
 SAF_API void ambi_bin_create(void** const phAmbi);                                 /* ambi_bin.h:161 */

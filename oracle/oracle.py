@@ -330,6 +330,29 @@ class AmbiEnc:
             lib().orc_ambi_enc_destroy(C.byref(self.h))
 
 
+class Rotator:
+    def __init__(self, frameSize=64):
+        self.h = vp()
+        self.F = frameSize
+        lib().orc_rotator_create(C.byref(self.h), frameSize)
+        for g in ("Yaw", "Pitch", "Roll", "QuaternionW", "QuaternionX", "QuaternionY", "QuaternionZ"):
+            getattr(lib(), "orc_rotator_get" + g).restype = C.c_float
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_rotator_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nOut, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((nOut, self.F), np.float32)
+        lib().orc_rotator_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, x.shape[1] if nSamples is None else nSamples)
+        return y
+
+    def __del__(self):
+        if self.h:
+            lib().orc_rotator_destroy(C.byref(self.h))
+
+
 class MatrixConv:
     def __init__(self, hop, H, part=1):
         H = np.ascontiguousarray(H, np.float32)

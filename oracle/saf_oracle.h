@@ -205,6 +205,14 @@ void orc_getSHrotMtxReal(const float Rxyz[9], float* RotMtx /* (L+1)^2 x (L+1)^2
 void orc_yawPitchRoll2Rzyx(float yaw, float pitch, float roll, int rollPitchYawFLAG, float R[9]);
 void orc_diffuseFieldEqualiseHRTFs_full(int N, const float* itds_s, const float* centreFreq, int nBands, const float* weights, int applyEQ, int applyPhase, orc_cpx* hrtfs);
 /* method: 1 LS, 2 LSDIFFEQ, 3 SPR, 4 TA, 5 MAGLS (BINAURAL_AMBI_DECODER_METHODS, saf_hoa.h:134-171); hrtfs [nBands][2][N]; decMtx [nBands][2][nSH] */
+/* ---- rotator example and quaternion helpers (orc_rotator.c) ---- */
+void orc_quaternion2rotationMatrix(const float q[4] /* w x y z */, float R[9]);
+void orc_euler2Quaternion(float alpha, float beta, float gamma, int convention /* 2 ypr, 3 rpy */, float q[4]);
+void orc_quaternion2euler(const float q[4], int convention, float* alpha, float* beta, float* gamma);
+void orc_rotator_create(void** ph, int frameSize);
+void orc_rotator_destroy(void** ph);
+void orc_rotator_init(void* h, int fs);
+void orc_rotator_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
 void orc_getBinauralAmbiDecoderFilters(const orc_cpx* hrtfs, const float* dirs_deg, int N, int fftSize, float fs, int method, int order,
                                        const float* itd_s, const float* weights, int diffMatching, int maxRE, float* decFilters /* [2][nSH][fftSize] */);
 void orc_getBinauralAmbiDecoderMtx(const orc_cpx* hrtfs, const float* dirs_deg, int N, int nBands, int method, int order, const float* freqVector,

@@ -282,6 +282,18 @@ def load():
     sig("saf_rfft_backward", None, vp, vp, fp)
     for m in ("matrixconv", "multiconv", "tvconv"):
         sig(m + "_getFrameSize", ci)
+    sig("quaternion2rotationMatrix", None, fp, fp); sig("rotationMatrix2quaternion", None, fp, fp)
+    sig("euler2Quaternion", None, cf, cf, cf, ci, ci, fp); sig("quaternion2euler", None, fp, ci, ci, fp, fp, fp)
+    sig("saf_hip_rotator_setFrameSize", None, ci)
+    sig("rotator_create", None, C.POINTER(vp)); sig("rotator_destroy", None, C.POINTER(vp)); sig("rotator_init", None, vp, ci)
+    sig("rotator_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("saf_hip_rotator_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci, ci)
+    sig("rotator_getFrameSize", ci); sig("rotator_getProcessingDelay", ci)
+    for g in ("Yaw", "Pitch", "Roll", "QuaternionW", "QuaternionX", "QuaternionY", "QuaternionZ"):
+        sig("rotator_set" + g, None, vp, cf); sig("rotator_get" + g, cf, vp)
+    for g in ("FlipYaw", "FlipPitch", "FlipRoll", "FlipQuaternion", "ChOrder", "NormType", "Order", "RPYflag"):
+        sig("rotator_set" + g, None, vp, ci); sig("rotator_get" + g, ci, vp)
+    sig("rotator_getNSHrequired", ci, vp)
     sig("tvconv_create", None, C.POINTER(vp)); sig("tvconv_destroy", None, C.POINTER(vp))
     sig("tvconv_init", None, vp, ci, ci)
     sig("tvconv_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)

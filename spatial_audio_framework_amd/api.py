@@ -511,6 +511,34 @@ class TvConvExample:
             self.L.tvconv_destroy(C.byref(self.h))
 
 
+class Rotator:
+    """rotator operator (examples/include/rotator.h)"""
+
+    def __init__(self, frameSize=64):
+        self.L = load(); self.h = vp(); self.F = frameSize
+        self.L.saf_hip_rotator_setFrameSize(frameSize)
+        self.L.rotator_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "rotator_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nOut, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.rotator_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def process_dev(self, d_in, in_strides, nIn, d_out, out_strides, nOut, nFrames):
+        """strides = (frame, ch) in floats"""
+        self.L.saf_hip_rotator_process_dev(self.h, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nOut, nFrames)
+
+    def __del__(self):
+        if getattr(self, "h", None) and C is not None:
+            self.L.rotator_destroy(C.byref(self.h))
+
+
 # ---------------------------------------------------------------- HRIR processing / binauraliser
 def estimateITDs(hrirs, fs):
     hrirs = np.ascontiguousarray(hrirs, np.float32)

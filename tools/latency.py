@@ -58,6 +58,10 @@ def main():
         x = frames(4, 32, 128)
         call, keep = direct(L.panner_process, pn.h, x, 64, 128)
         r = lat(call); r["op"] = "panner_process 32 sources -> 64 loudspeakers, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        ro = api.Rotator(128); ro.init(48000); ro.setOrder(7); ro.setYaw(30.0)
+        x = frames(6, 64, 128)
+        call, keep = direct(L.rotator_process, ro.h, x, 64, 128)
+        r = lat(call); r["op"] = "rotator_process order 7, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
         H = (np.random.default_rng(3).normal(size=(2, 256, 1024)) / 32).astype(np.float32)
         mc = api.MatrixConv(512, H, 1)
         xi = np.ascontiguousarray(frames(5, 256, 512)); yo = np.zeros((2, 512), np.float32)
