@@ -706,6 +706,43 @@ SAF_API int  rotator_getOrder(void* const hRot);
 SAF_API int  rotator_getNSHrequired(void* const hRot);
 SAF_API int  rotator_getProcessingDelay(void);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * beamformer: static axisymmetric beams over an Ambisonic scene (examples/include/beamformer.h:50-190;
+ * examples/src/beamformer/beamformer.c).  Same block path as ambi_enc with the beam weights as the matrix.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef enum { STATIC_BEAM_TYPE_CARDIOID = 1, STATIC_BEAM_TYPE_HYPERCARDIOID, STATIC_BEAM_TYPE_MAX_EV } STATIC_BEAM_TYPES;      /* _common.h:166-171 */
+SAF_API void beamWeightsCardioid2Spherical(int N, float* b_n);                                                   /* saf_sh.c:716 */
+SAF_API void beamWeightsHypercardioid2Spherical(int N, float* b_n);                                              /* saf_sh.c:733 */
+SAF_API void rotateAxisCoeffsReal(int order, float* c_n, float theta_0, float phi_0, float* c_nm);               /* saf_sh.c:839 (inclination, azimuth in rad) */
+/** Replaces -DBEAMFORMER_FRAME_SIZE (default 128); call before beamformer_create. */
+SAF_API void saf_hip_beamformer_setFrameSize(int frameSize);
+SAF_API void beamformer_create(void** const phBeam);                               /* beamformer.h:56 */
+SAF_API void beamformer_destroy(void** const phBeam);                              /* beamformer.h:63 */
+SAF_API void beamformer_init(void* const hBeam, int samplerate);                   /* beamformer.h:71 */
+SAF_API void beamformer_process(void* const hBeam, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples);   /* beamformer.h:84 */
+/** nFrames consecutive blocks of device-resident ACN signals with the beams set before the call (the cross-fade, if any, is on the first block). */
+SAF_API void saf_hip_beamformer_process_dev(void* const hBeam, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                            float* d_out, long long out_frame_stride, long long out_ch_stride, int nOutputs, int nFrames);
+SAF_API void beamformer_refreshSettings(void* const hBeam);                        /* beamformer.h:100-134 */
+SAF_API void beamformer_setBeamOrder(void* const hBeam, int newValue);
+SAF_API void beamformer_setBeamAzi_deg(void* const hBeam, int index, float newAzi_deg);
+SAF_API void beamformer_setBeamElev_deg(void* const hBeam, int index, float newElev_deg);
+SAF_API void beamformer_setNumBeams(void* const hBeam, int new_nBeams);
+SAF_API void beamformer_setChOrder(void* const hBeam, int newOrder);
+SAF_API void beamformer_setNormType(void* const hBeam, int newType);
+SAF_API void beamformer_setBeamType(void* const hBeam, int newID);
+SAF_API int  beamformer_getFrameSize(void);                                        /* beamformer.h:145-189 */
+SAF_API int  beamformer_getBeamOrder(void* const hBeam);
+SAF_API float beamformer_getBeamAzi_deg(void* const hBeam, int index);
+SAF_API float beamformer_getBeamElev_deg(void* const hBeam, int index);
+SAF_API int  beamformer_getNumBeams(void* const hBeam);
+SAF_API int  beamformer_getMaxNumBeams(void);
+SAF_API int  beamformer_getNSHrequired(void* const hBeam);
+SAF_API int  beamformer_getChOrder(void* const hBeam);
+SAF_API int  beamformer_getNormType(void* const hBeam);
+SAF_API int  beamformer_getBeamType(void* const hBeam);
+SAF_API int  beamformer_getProcessingDelay(void);
+
 /** Replaces -DAMBI_BIN_FRAME_SIZE; call before ambi_bin_create. */
 SAF_API void saf_hip_ambi_bin_setFrameSize(int frameSize);
 SAF_API void ambi_bin_create(void** const phAmbi);                                 /* ambi_bin.h:161 */

@@ -330,6 +330,37 @@ class AmbiEnc:
             lib().orc_ambi_enc_destroy(C.byref(self.h))
 
 
+class Beamformer:
+    def __init__(self, frameSize=128):
+        self.h = vp()
+        self.F = frameSize
+        lib().orc_beamformer_create(C.byref(self.h), frameSize)
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_beamformer_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nOut, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((nOut, self.F), np.float32)
+        lib().orc_beamformer_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, x.shape[1] if nSamples is None else nSamples)
+        return y
+
+    def __del__(self):
+        if self.h:
+            lib().orc_beamformer_destroy(C.byref(self.h))
+
+
+def rotateAxisCoeffsReal(order, c_n, theta_0, phi_0):
+    c = np.ascontiguousarray(c_n, np.float32); out = np.zeros((order + 1) ** 2, np.float32)
+    lib().orc_rotateAxisCoeffsReal(order, fptr(c), C.c_float(theta_0), C.c_float(phi_0), fptr(out)); return out
+
+
+def beamWeights(kind, N):
+    b = np.zeros(N + 1, np.float32)
+    {1: lib().orc_beamWeightsCardioid2Spherical, 2: lib().orc_beamWeightsHypercardioid2Spherical, 3: lib().orc_beamWeightsMaxEV}[kind](N, fptr(b)); return b
+
+
 class Rotator:
     def __init__(self, frameSize=64):
         self.h = vp()

@@ -284,6 +284,19 @@ def load():
         sig(m + "_getFrameSize", ci)
     sig("quaternion2rotationMatrix", None, fp, fp); sig("rotationMatrix2quaternion", None, fp, fp)
     sig("euler2Quaternion", None, cf, cf, cf, ci, ci, fp); sig("quaternion2euler", None, fp, ci, ci, fp, fp, fp)
+    sig("beamWeightsCardioid2Spherical", None, ci, fp); sig("beamWeightsHypercardioid2Spherical", None, ci, fp)
+    sig("rotateAxisCoeffsReal", None, ci, fp, cf, cf, fp)
+    sig("saf_hip_beamformer_setFrameSize", None, ci)
+    sig("beamformer_create", None, C.POINTER(vp)); sig("beamformer_destroy", None, C.POINTER(vp)); sig("beamformer_init", None, vp, ci)
+    sig("beamformer_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("saf_hip_beamformer_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci, ci)
+    sig("beamformer_refreshSettings", None, vp)
+    for g in ("BeamOrder", "NumBeams", "ChOrder", "NormType", "BeamType"):
+        sig("beamformer_set" + g, None, vp, ci); sig("beamformer_get" + g, ci, vp)
+    for g in ("BeamAzi_deg", "BeamElev_deg"):
+        sig("beamformer_set" + g, None, vp, ci, cf); sig("beamformer_get" + g, cf, vp, ci)
+    sig("beamformer_getFrameSize", ci); sig("beamformer_getMaxNumBeams", ci); sig("beamformer_getProcessingDelay", ci)
+    sig("beamformer_getNSHrequired", ci, vp)
     sig("saf_hip_rotator_setFrameSize", None, ci)
     sig("rotator_create", None, C.POINTER(vp)); sig("rotator_destroy", None, C.POINTER(vp)); sig("rotator_init", None, vp, ci)
     sig("rotator_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)

@@ -511,6 +511,45 @@ class TvConvExample:
             self.L.tvconv_destroy(C.byref(self.h))
 
 
+class Beamformer:
+    """beamformer operator (examples/include/beamformer.h)"""
+
+    def __init__(self, frameSize=128):
+        self.L = load(); self.h = vp(); self.F = frameSize
+        self.L.saf_hip_beamformer_setFrameSize(frameSize)
+        self.L.beamformer_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "beamformer_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nOut, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.beamformer_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def process_dev(self, d_in, in_strides, nIn, d_out, out_strides, nOut, nFrames):
+        """strides = (frame, ch) in floats"""
+        self.L.saf_hip_beamformer_process_dev(self.h, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nOut, nFrames)
+
+    def __del__(self):
+        if getattr(self, "h", None) and C is not None:
+            self.L.beamformer_destroy(C.byref(self.h))
+
+
+def rotateAxisCoeffsReal(order, c_n, theta_0, phi_0):
+    c = np.ascontiguousarray(c_n, np.float32); out = np.zeros((order + 1) ** 2, np.float32)
+    load().rotateAxisCoeffsReal(order, _f(c), C.c_float(theta_0), C.c_float(phi_0), _f(out)); return out
+
+
+def beamWeights(kind, N):
+    """kind: 1 cardioid, 2 hyper-cardioid, 3 max-EV -> b_n[N+1]"""
+    b = np.zeros(N + 1, np.float32)
+    {1: load().beamWeightsCardioid2Spherical, 2: load().beamWeightsHypercardioid2Spherical, 3: load().beamWeightsMaxEV}[kind](N, _f(b)); return b
+
+
 class Rotator:
     """rotator operator (examples/include/rotator.h)"""
 

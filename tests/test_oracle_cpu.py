@@ -601,3 +601,35 @@ def test_reference_example_rotator_known_answer_oracle():
     R = np.zeros(9, np.float32)
     O.lib().orc_quaternion2rotationMatrix(q.ctypes.data_as(O.c_f), R.ctypes.data_as(O.c_f))
     assert np.abs(R.reshape(3, 3)[::-1, ::-1] - O.yawPitchRoll2Rzyx(*ypr, 0)).max() < 1e-6
+
+
+def test_beamformer_weights_closed_forms():
+    """rotateAxisCoeffsReal and the static beam weights (saf_sh.c:716-745, 839-882; the reference has no test for them):
+    steering an axisymmetric pattern to (theta0, phi0) gives sqrt(4 pi / (2n+1)) c_n Y_nm^real(theta0, phi0); the cardioid
+    of order N has the pattern ((1 + cos g) / 2)^N; the hyper-cardioid has its maximum, sqrt(4 pi) for an N3D plane wave,
+    in the look direction — all evaluated through the oracle's real SH."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(2)
+    for order in (1, 3, 6):
+        c = rng.normal(size=order + 1).astype(np.float32)
+        az, incl = 0.7, 1.1
+        w = O.rotateAxisCoeffsReal(order, c, incl, az)
+        Y = O.getSHreal(order, np.array([[az, incl]], np.float32))[:, 0]
+        ref = np.concatenate([np.full(2 * n + 1, np.sqrt(4 * np.pi / (2 * n + 1)) * c[n]) for n in range(order + 1)]) * Y
+        assert np.abs(w - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+    # patterns: response of the steered weights to N3D plane waves on a great circle through the look direction
+    look = np.array([[30.0, 20.0]], np.float32)
+    g = np.radians(np.linspace(0, 180, 37))
+    # directions at angle g from the look direction (rotate about an axis perpendicular to it)
+    u = np.array([np.cos(np.radians(20)) * np.cos(np.radians(30)), np.cos(np.radians(20)) * np.sin(np.radians(30)), np.sin(np.radians(20))])
+    a = np.cross(u, [0, 0, 1.0]); a /= np.linalg.norm(a); b = np.cross(a, u)
+    pts = np.cos(g)[:, None] * u + np.sin(g)[:, None] * b
+    dirs = np.stack([np.degrees(np.arctan2(pts[:, 1], pts[:, 0])), np.degrees(np.arcsin(np.clip(pts[:, 2], -1, 1)))], 1).astype(np.float32)
+    for N in (1, 2, 4):
+        Yn3d = O.getRSH(N, dirs)                                     # [nSH][37], N3D
+        w = O.rotateAxisCoeffsReal(N, O.beamWeights(1, N), np.pi / 2 - np.radians(20.0), np.radians(30.0))
+        resp = w @ Yn3d
+        assert np.abs(resp / resp[0] - ((1 + np.cos(g)) / 2) ** N).max() < 1e-5
+        wh = O.rotateAxisCoeffsReal(N, O.beamWeights(2, N), np.pi / 2 - np.radians(20.0), np.radians(30.0))
+        rh = wh @ Yn3d
+        assert abs(rh[0] - np.sqrt(4 * np.pi)) < 1e-5 and np.abs(rh).max() <= rh[0] + 1e-6    # on-axis gain sqrt(4 pi) (N3D signals carry sqrt(4 pi) Y), maximum there
