@@ -10,8 +10,8 @@
  * the SN3D / FuMa -> N3D scaling as the per-row input gain.  The weights are built on the host:
  *   beamWeightsCardioid2Spherical / beamWeightsHypercardioid2Spherical (saf_sh.c:716-745), beamWeightsMaxEV (:747),
  *   rotateAxisCoeffsReal (saf_sh.c:839-882 via getSHcomplex :333-382 and complex2realCoeffs :384-475).
- * The reference holds no test for this operator ("parity unpinned"): tests compare with the oracle's literal restatement
- * and with the closed-form beam patterns.
+ * The reference holds no test for this operator ("parity unpinned"): tests/ compares with a literal CPU restatement and
+ * with the closed-form beam patterns.
  */
 #include "saf_hip_common.h"
 #include "../../include/saf_hip.h"
