@@ -276,6 +276,25 @@ def main():
                 "batch": f"1 handle x {nF} blocks per call", "kernels_ms": per,
                 "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": 66 * F * 4, "path_achieved_GBps": round(66 * F * 4 * nF / t / 1e9, 1), "peak_GBps": HBM},
                 "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s", "cores": 1, "kind": "port"}})
+    # ---- rotator and beamformer (beyond SURVEY 8f): order 7, 64 blocks of 256 samples per call, device-resident
+    F, nF, nSH = 256, 64, 64
+    gr = api.Rotator(F); gr.init(48000); gr.setOrder(7); gr.setYaw(35.0); gr.setPitch(-10.0)
+    x = torch.rand(nSH, nF * F, device="cuda") * 2 - 1; y = torch.zeros(nSH, nF * F, device="cuda")
+    t, per = timed(L, torch, lambda: gr.process_dev(x.data_ptr(), (F, nF * F), nSH, y.data_ptr(), (F, nF * F), nSH, nF), steps, warm, ["sh_encode"])
+    orr = O.Rotator(F); orr.init(48000); orr.setOrder(7); orr.setYaw(35.0); xb = frames(31, nSH, F)
+    tc = cpu_time(lambda: orr.process(xb, nSH), 3.0)
+    out.append({"config": "rotator: order 7 scene rotation, 256-sample blocks", "value": round(nF / t, 1), "unit": "frames/s",
+                "batch": f"1 handle x {nF} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": 2 * nSH * F * 4, "path_achieved_GBps": round(2 * nSH * F * 4 * nF / t / 1e9, 1), "peak_GBps": HBM},
+                "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s", "cores": 1, "kind": "port"}})
+    gb = api.Beamformer(F); gb.init(48000); gb.setBeamOrder(7); gb.setNumBeams(64); gb.setNormType(1)
+    t, per = timed(L, torch, lambda: gb.process_dev(x.data_ptr(), (F, nF * F), nSH, y.data_ptr(), (F, nF * F), 64, nF), steps, warm, ["sh_encode"])
+    ob = O.Beamformer(F); ob.init(48000); ob.setBeamOrder(7); ob.setNumBeams(64); ob.setNormType(1)
+    tc = cpu_time(lambda: ob.process(xb, 64), 3.0)
+    out.append({"config": "beamformer: 64 hyper-cardioid beams of order 7, 256-sample blocks", "value": round(nF / t, 1), "unit": "frames/s",
+                "batch": f"1 handle x {nF} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": 2 * nSH * F * 4, "path_achieved_GBps": round(2 * nSH * F * 4 * nF / t / 1e9, 1), "peak_GBps": HBM},
+                "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s", "cores": 1, "kind": "port"}})
     for o in out:
         print(json.dumps(o), flush=True)
 
