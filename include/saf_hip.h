@@ -743,6 +743,49 @@ SAF_API int  beamformer_getNormType(void* const hBeam);
 SAF_API int  beamformer_getBeamType(void* const hBeam);
 SAF_API int  beamformer_getProcessingDelay(void);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * ambi_drc: frequency-dependent dynamic range compression of an Ambisonic scene (examples/include/ambi_drc.h:97-270;
+ * examples/src/ambi_drc/ambi_drc.c).  afSTFT analysis -> per-band gain from the omni channel -> synthesis.
+ * ---------------------------------------------------------------------------------------------------------- */
+/** Replaces -DAMBI_DRC_FRAME_SIZE (default 128); call before ambi_drc_create. */
+SAF_API void saf_hip_ambi_drc_setFrameSize(int frameSize);
+SAF_API void ambi_drc_create(void** const phAmbi);                                  /* ambi_drc.h:103 */
+SAF_API void ambi_drc_destroy(void** const phAmbi);                                 /* ambi_drc.h:110 */
+SAF_API void ambi_drc_init(void* const hAmbi, int samplerate);                      /* ambi_drc.h:118 */
+SAF_API void ambi_drc_process(void* const hAmbi, const float* const* inputs, float** const outputs, int nCH, int nSamples);   /* ambi_drc.h:131 */
+/** nFrames consecutive blocks of device-resident signals (the display ring is not fed by this entry). */
+SAF_API void saf_hip_ambi_drc_process_dev(void* const hAmbi, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                          float* d_out, long long out_frame_stride, long long out_ch_stride, int nFrames);
+SAF_API void ambi_drc_refreshSettings(void* const hAmbi);                           /* ambi_drc.h:146-189 */
+SAF_API void ambi_drc_setThreshold(void* const hAmbi, float newValue);
+SAF_API void ambi_drc_setRatio(void* const hAmbi, float newValue);
+SAF_API void ambi_drc_setKnee(void* const hAmbi, float newValue);
+SAF_API void ambi_drc_setInGain(void* const hAmbi, float newValue);
+SAF_API void ambi_drc_setOutGain(void* const hAmbi, float newValue);
+SAF_API void ambi_drc_setAttack(void* const hAmbi, float newValue);
+SAF_API void ambi_drc_setRelease(void* const hAmbi, float newValue);
+SAF_API void ambi_drc_setChOrder(void* const hAmbi, int newOrder);
+SAF_API void ambi_drc_setNormType(void* const hAmbi, int newType);
+SAF_API void ambi_drc_setInputPreset(void* const hAmbi, SH_ORDERS newPreset);
+SAF_API int  ambi_drc_getFrameSize(void);                                           /* ambi_drc.h:200-268 */
+SAF_API float** ambi_drc_getGainTF(void* const hAmbi);                              /* [133][3000] gain factors of the last 8 s */
+SAF_API int  ambi_drc_getGainTFwIdx(void* const hAmbi);
+SAF_API int  ambi_drc_getGainTFrIdx(void* const hAmbi);
+SAF_API float* ambi_drc_getFreqVector(void* const hAmbi, int* nFreqPoints);
+SAF_API float ambi_drc_getThreshold(void* const hAmbi);
+SAF_API float ambi_drc_getRatio(void* const hAmbi);
+SAF_API float ambi_drc_getKnee(void* const hAmbi);
+SAF_API float ambi_drc_getInGain(void* const hAmbi);
+SAF_API float ambi_drc_getOutGain(void* const hAmbi);
+SAF_API float ambi_drc_getAttack(void* const hAmbi);
+SAF_API float ambi_drc_getRelease(void* const hAmbi);
+SAF_API int  ambi_drc_getChOrder(void* const hAmbi);
+SAF_API int  ambi_drc_getNormType(void* const hAmbi);
+SAF_API SH_ORDERS ambi_drc_getInputPreset(void* const hAmbi);
+SAF_API int  ambi_drc_getNSHrequired(void* const hAmbi);
+SAF_API int  ambi_drc_getSamplerate(void* const hAmbi);
+SAF_API int  ambi_drc_getProcessingDelay(void);
+
 /** Replaces -DAMBI_BIN_FRAME_SIZE; call before ambi_bin_create. */
 SAF_API void saf_hip_ambi_bin_setFrameSize(int frameSize);
 SAF_API void ambi_bin_create(void** const phAmbi);                                 /* ambi_bin.h:161 */

@@ -330,6 +330,31 @@ class AmbiEnc:
             lib().orc_ambi_enc_destroy(C.byref(self.h))
 
 
+class AmbiDrc:
+    def __init__(self, frameSize=128):
+        self.h = vp()
+        self.F = frameSize
+        lib().orc_ambi_drc_create(C.byref(self.h), frameSize)
+        lib().orc_ambi_drc_getLastGains.restype = c_f
+
+    def __getattr__(self, name):
+        fn = getattr(lib(), "orc_ambi_drc_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.zeros((x.shape[0], self.F), np.float32)
+        lib().orc_ambi_drc_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], x.shape[1] if nSamples is None else nSamples)
+        return y
+
+    def lastGains(self):
+        return np.ctypeslib.as_array(lib().orc_ambi_drc_getLastGains(self.h), shape=(133, self.F // 128)).copy()
+
+    def __del__(self):
+        if self.h:
+            lib().orc_ambi_drc_destroy(C.byref(self.h))
+
+
 class Beamformer:
     def __init__(self, frameSize=128):
         self.h = vp()

@@ -205,6 +205,12 @@ void orc_getSHrotMtxReal(const float Rxyz[9], float* RotMtx /* (L+1)^2 x (L+1)^2
 void orc_yawPitchRoll2Rzyx(float yaw, float pitch, float roll, int rollPitchYawFLAG, float R[9]);
 void orc_diffuseFieldEqualiseHRTFs_full(int N, const float* itds_s, const float* centreFreq, int nBands, const float* weights, int applyEQ, int applyPhase, orc_cpx* hrtfs);
 /* method: 1 LS, 2 LSDIFFEQ, 3 SPR, 4 TA, 5 MAGLS (BINAURAL_AMBI_DECODER_METHODS, saf_hoa.h:134-171); hrtfs [nBands][2][N]; decMtx [nBands][2][nSH] */
+/* ---- ambi_drc example (orc_ambi_drc.c) ---- */
+void orc_ambi_drc_create(void** ph, int frameSize);
+void orc_ambi_drc_destroy(void** ph);
+void orc_ambi_drc_init(void* h, int fs);
+void orc_ambi_drc_process(void* h, const float* const* inputs, float* const* outputs, int nCh, int nSamples);
+const float* orc_ambi_drc_getLastGains(void* h);      /* [133][T] gain factors of the last block */
 /* ---- beamformer example and its SH helpers (orc_beamformer.c) ---- */
 void orc_rotateAxisCoeffsReal(int order, const float* c_n, float theta_0 /* inclination */, float phi_0 /* azimuth */, float* c_nm);
 void orc_beamWeightsCardioid2Spherical(int N, float* b_n);

@@ -297,6 +297,19 @@ def load():
         sig("beamformer_set" + g, None, vp, ci, cf); sig("beamformer_get" + g, cf, vp, ci)
     sig("beamformer_getFrameSize", ci); sig("beamformer_getMaxNumBeams", ci); sig("beamformer_getProcessingDelay", ci)
     sig("beamformer_getNSHrequired", ci, vp)
+    sig("saf_hip_ambi_drc_setFrameSize", None, ci)
+    sig("ambi_drc_create", None, C.POINTER(vp)); sig("ambi_drc_destroy", None, C.POINTER(vp)); sig("ambi_drc_init", None, vp, ci)
+    sig("ambi_drc_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci)
+    sig("saf_hip_ambi_drc_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci)
+    sig("ambi_drc_refreshSettings", None, vp)
+    for g in ("Threshold", "Ratio", "Knee", "InGain", "OutGain", "Attack", "Release"):
+        sig("ambi_drc_set" + g, None, vp, cf); sig("ambi_drc_get" + g, cf, vp)
+    for g in ("ChOrder", "NormType", "InputPreset"):
+        sig("ambi_drc_set" + g, None, vp, ci); sig("ambi_drc_get" + g, ci, vp)
+    sig("ambi_drc_getFrameSize", ci); sig("ambi_drc_getProcessingDelay", ci)
+    for g in ("GainTFwIdx", "GainTFrIdx", "NSHrequired", "Samplerate"):
+        sig("ambi_drc_get" + g, ci, vp)
+    sig("ambi_drc_getGainTF", C.POINTER(fp), vp); sig("ambi_drc_getFreqVector", fp, vp, ip)
     sig("saf_hip_rotator_setFrameSize", None, ci)
     sig("rotator_create", None, C.POINTER(vp)); sig("rotator_destroy", None, C.POINTER(vp)); sig("rotator_init", None, vp, ci)
     sig("rotator_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)

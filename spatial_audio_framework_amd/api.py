@@ -511,6 +511,39 @@ class TvConvExample:
             self.L.tvconv_destroy(C.byref(self.h))
 
 
+class AmbiDrc:
+    """ambi_drc operator (examples/include/ambi_drc.h)"""
+
+    def __init__(self, frameSize=128):
+        self.L = load(); self.h = vp(); self.F = frameSize
+        self.L.saf_hip_ambi_drc_setFrameSize(frameSize)
+        self.L.ambi_drc_create(C.byref(self.h))
+
+    def __getattr__(self, name):
+        fn = getattr(load(), "ambi_drc_" + name)
+        return lambda *a: fn(self.h, *[C.c_float(x) if isinstance(x, float) else x for x in a])
+
+    def process(self, x, nSamples=None):
+        """x [nCh][F] -> y [nCh][F] (the reference's process has one channel count for both)"""
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((x.shape[0], max(ns, self.F)), np.nan, np.float32)
+        self.L.ambi_drc_process(self.h, _rows(x), _rows(y), x.shape[0], ns)
+        return y[:, :self.F]
+
+    def process_dev(self, d_in, in_strides, nIn, d_out, out_strides, nFrames):
+        self.L.saf_hip_ambi_drc_process_dev(self.h, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nFrames)
+
+    def gainTF(self):
+        """display ring [133][3000] of the bank being written, write index"""
+        rows = self.L.ambi_drc_getGainTF(self.h)
+        return np.stack([np.ctypeslib.as_array(rows[b], shape=(3000,)).copy() for b in range(133)]), self.L.ambi_drc_getGainTFwIdx(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None) and C is not None:
+            self.L.ambi_drc_destroy(C.byref(self.h))
+
+
 class Beamformer:
     """beamformer operator (examples/include/beamformer.h)"""
 

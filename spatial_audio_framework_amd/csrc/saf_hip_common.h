@@ -138,6 +138,16 @@ struct SynLaunch {
 };
 void launch_synthesis(const SynLaunch& s);
 
+/* ---- per-band dynamic range compression on the spectra (drc_kernels.hip; ambi_drc.c:168-199) ---- */
+struct DrcLaunch {
+    float2* X; long long x_band, x_ch;        /* spectra [band][ch][hop], compressed in place */
+    float* gains; long long g_band;           /* out: gain factor per (band, hop) of this call */
+    float* yL_z1;                             /* [133] peak detector state */
+    float boost, makeup, threshold, ratio, knee, alpha_a, alpha_r, floor;
+    int nCh, H;
+};
+void launch_drc(const DrcLaunch& l);
+
 /* ---- afSTFT analysis -> synthesis of the SAME signal without the transforms (afstft_kernels.hip) ----
  * When nothing band-dependent happens between afSTFT_forward and afSTFT_backward, the 256-point FFT and its inverse
  * cancel and the hybrid split / merge reduces to its 3-hop delay: what remains is the window fold, a delay and the
