@@ -62,6 +62,9 @@ def generate(O):
     out["ambi_dec_bin_small"] = {"out": ambi_dec_bin_scenario(O.AmbiDec)}
     out["pmaps_small"] = pmaps_scenario(O)
     out["ambi_bin_small"] = {"out": ambi_bin_scenario(O.AmbiBin)}
+    out["rotator_small"] = {"out": rotator_scenario(O.Rotator)}
+    out["beamformer_small"] = {"out": beamformer_scenario(O.Beamformer)}
+    out["ambi_drc_small"] = {"out": ambi_drc_scenario(O.AmbiDrc)}
     return out
 
 
@@ -153,6 +156,45 @@ def ambi_enc_scenario(cls, F=256, nFrames=8):
             e.setSourceGain(2, 1.5)
         ys.append(e.process(x[:, f * F:(f + 1) * F], 18))
     return np.concatenate(ys, 1)
+
+
+def rotator_scenario(cls, F=64, nB=10, order=3):
+    """order 3; rotation set by Euler angles before block 2, by quaternion before block 6"""
+    r = cls(F); r.init(48000); r.setOrder(order)
+    x = frames(505, (order + 1) ** 2, nB * F)
+    ys = []
+    for b in range(nB):
+        if b == 2:
+            r.setYaw(50.0); r.setPitch(-20.0); r.setRoll(15.0)
+        if b == 6:
+            r.setQuaternionW(0.7071068); r.setQuaternionX(0.0); r.setQuaternionY(0.7071068); r.setQuaternionZ(0.0)
+        ys.append(r.process(np.ascontiguousarray(x[:, b * F:(b + 1) * F]), (order + 1) ** 2))
+    return np.concatenate(ys, 1)
+
+
+def beamformer_scenario(cls, F=128, nB=8, order=4):
+    """order 4, SN3D input, 5 beams; hyper-cardioid, a beam moved before block 3, cardioid from block 5"""
+    b = cls(F); b.init(48000); b.setBeamOrder(order); b.setNumBeams(5)
+    x = frames(606, (order + 1) ** 2, nB * F)
+    ys = []
+    for k in range(nB):
+        if k == 3:
+            b.setBeamAzi_deg(1, 100.0); b.setBeamElev_deg(1, -40.0)
+        if k == 5:
+            b.setBeamType(1)
+        ys.append(b.process(np.ascontiguousarray(x[:, k * F:(k + 1) * F]), 5))
+    return np.concatenate(ys, 1)
+
+
+def ambi_drc_scenario(cls, F=128, nB=48, order=2):
+    """order 2; quiet / loud / quiet input, threshold -35 dB, ratio 6, knee 4 dB, 20 ms attack, 120 ms release"""
+    d = cls(F)
+    d.setInputPreset(order); d.setThreshold(-35.0); d.setRatio(6.0); d.setKnee(4.0); d.setAttack(20.0); d.setRelease(120.0); d.setInGain(3.0)
+    d.init(48000)
+    x = frames(707, (order + 1) ** 2, nB * F)
+    env = np.ones(nB * F, np.float32); env[: nB * F // 3] = 0.02; env[2 * nB * F // 3:] = 0.05
+    x = (x * env).astype(np.float32)
+    return np.concatenate([d.process(np.ascontiguousarray(x[:, k * F:(k + 1) * F])) for k in range(nB)], 1)
 
 
 if __name__ == "__main__":

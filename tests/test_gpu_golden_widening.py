@@ -49,3 +49,10 @@ def test_golden_activity_maps(saf, orc):
         inv = 1.0 / gen(order, Cx, Yg, 2)
         assert np.abs(inv - ref[k]).max() < 5e-6 * ref[k].max() + 3e-8, k
         assert set(np.argsort(inv)[:2]) == {139, 204}
+
+
+def test_golden_rotator_beamformer_ambi_drc(saf):
+    """the operators beyond SURVEY 8f on their committed fixtures"""
+    assert relrms(mg.rotator_scenario(saf.Rotator), np.load(GOLD / "rotator_small.npz")["out"]) < 2e-6
+    assert relrms(mg.beamformer_scenario(saf.Beamformer), np.load(GOLD / "beamformer_small.npz")["out"]) < 2e-6
+    assert relrms(mg.ambi_drc_scenario(saf.AmbiDrc), np.load(GOLD / "ambi_drc_small.npz")["out"]) < TOL
