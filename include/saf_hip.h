@@ -420,6 +420,41 @@ SAF_API void saf_hip_binauraliser_getHRTFfb(void* const hBin, float_complex* hrt
 SAF_API void saf_hip_binauraliser_getHRTFinterp(void* const hBin, float_complex* hrtf_interp);/* [nSources][133][2] */
 
 /* ========================================================================== */
+/*      binauraliser_nf (examples/include/binauraliser_nf.h:76-194)           */
+/* ========================================================================== */
+/** A handle from binauraliserNF_create is a binauraliser handle with a distance per source: every binauraliser_* setter and
+ *  getter above applies to it (the reference's NF struct begins with the binauraliser members, binauraliser_nf_internal.h:61-137)
+ *  and it is accepted by saf_hip_binauraliser_batch_create (all instances of a batch NF, or none).  Sources nearer than the
+ *  far-field threshold (34 head radii) get the DVF shelf of their lateral angle and distance on each ear.
+ *  binauraliserNF_processFD (binauraliser_nf.h:135) is declared by the reference but has no definition there; not provided. */
+SAF_API void binauraliserNF_create(void** const phBin);                              /* binauraliser_nf.h:76 */
+SAF_API void binauraliserNF_destroy(void** const phBin);                             /* binauraliser_nf.h:83 */
+SAF_API void binauraliserNF_init(void* const hBin, int samplerate);                  /* binauraliser_nf.h:93 */
+SAF_API void binauraliserNF_initCodec(void* const hBin);                             /* binauraliser_nf.h:112 */
+SAF_API void binauraliserNF_process(void* const hBin, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* binauraliser_nf.h:124 */
+SAF_API void binauraliserNF_setSourceDist_m(void* const hBin, int index, float newDist_m);   /* binauraliser_nf.h:154 */
+SAF_API void binauraliserNF_setInputConfigPreset(void* const hBin, int newPresetID); /* binauraliser_nf.h:163 */
+SAF_API float binauraliserNF_getSourceDist_m(void* const hBin, int index);           /* binauraliser_nf.h:177 */
+SAF_API float binauraliserNF_getFarfieldThresh_m(void* const hBin);                  /* binauraliser_nf.h:183 */
+SAF_API float binauraliserNF_getFarfieldHeadroom(void* const hBin);                  /* binauraliser_nf.h:189 */
+SAF_API float binauraliserNF_getNearfieldLimit_m(void* const hBin);                  /* binauraliser_nf.h:194 */
+/** Device-pointer entry, layout of saf_hip_binauraliser_process_dev. */
+SAF_API void saf_hip_binauraliserNF_process_dev(void* const hBin, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                                float* d_out, long long out_frame_stride, long long out_ch_stride, int nFrames);
+/** Read-back for parity checks: the filters the band MAC applies, [nSources][133][2] (HRTF x DVF response for near sources). */
+SAF_API void saf_hip_binauraliserNF_getHRTFnf(void* const hBin, float_complex* hrtf_nf);
+
+/* ---- near-field DVF filters (framework/modules/saf_utilities/saf_utility_dvf.h:62-153) and the response of a filter at given
+ *      frequencies (saf_utility_filters.h, evalIIRTransferFunctionf; saf_utility_filters.c:609-671).  Host functions. ---- */
+SAF_API void calcDVFCoeffs(float alpha, float rho, float fs, float* b, float* a);                                /* saf_utility_dvf.h:62 */
+SAF_API void interpDVFShelfParams(float theta, float rho, float* iG0, float* iGInf, float* iFc);                 /* saf_utility_dvf.h:82 */
+SAF_API void dvfShelfCoeffs(float g0, float gInf, float fc, float fs, float* b0, float* b1, float* a1);          /* saf_utility_dvf.h:102 */
+SAF_API void calcDVFShelfParams(int i, float rho, float* g0, float* gInf, float* fc);                            /* saf_utility_dvf.h:124 */
+SAF_API void doaToIpsiInteraural(float azimuth, float elevation, float* alphaLR, float* betaLR);                 /* saf_utility_dvf.h:149 */
+SAF_API void evalIIRTransferFunctionf(float* b_coeff, float* a_coeff, int nCoeffs, float* freqs, int nFreqs, float fs, int mag2dB,
+                                      float* magnitude, float* phase_rad);
+
+/* ========================================================================== */
 /*      powermap (examples/include/powermap.h:87-371), PWD mode               */
 /* ========================================================================== */
 typedef enum { PM_MODE_PWD = 1, PM_MODE_MVDR, PM_MODE_CROPAC_LCMV, PM_MODE_MUSIC, PM_MODE_MUSIC_LOG, PM_MODE_MINNORM, PM_MODE_MINNORM_LOG } POWERMAP_MODES; /* powermap.h:58-74 */

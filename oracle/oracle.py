@@ -640,6 +640,91 @@ class Binauraliser:
             lib().orc_binauraliser_destroy(C.byref(self.h))
 
 
+class BinauraliserNF(Binauraliser):
+    """binauraliser_nf (examples/src/binauraliser_nf): a Binauraliser whose sources carry distances."""
+
+    def __init__(self, frameSize=128, maxSources=64):
+        self.h = vp()
+        self.F = frameSize
+        self.maxSources = maxSources
+        L = lib()
+        L.orc_binauraliserNF_create(C.byref(self.h), frameSize, maxSources)
+        for n in ("getITDs", "getWeights"):
+            getattr(L, "orc_binauraliser_" + n).restype = c_f
+        for n in ("getHRTFfb", "getHRTFinterp"):
+            getattr(L, "orc_binauraliser_" + n).restype = vp
+        for n in ("getSourceDist_m", "getFarfieldThresh_m", "getFarfieldHeadroom", "getNearfieldLimit_m"):
+            getattr(L, "orc_binauraliserNF_" + n).restype = C.c_float
+        for n in ("getDVFmags", "getDVFphases"):
+            getattr(L, "orc_binauraliserNF_" + n).restype = c_f
+
+    def process(self, x, nOut=2, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.zeros((nOut, self.F), np.float32)
+        lib().orc_binauraliserNF_process(self.h, _chan_ptrs(x), _chan_ptrs(y), x.shape[0], nOut, ns)
+        return y
+
+    def setSourceDist_m(self, i, d):
+        lib().orc_binauraliserNF_setSourceDist_m(self.h, i, C.c_float(d))
+
+    def getSourceDist_m(self, i):
+        return lib().orc_binauraliserNF_getSourceDist_m(self.h, i)
+
+    def getFarfieldThresh_m(self):
+        return lib().orc_binauraliserNF_getFarfieldThresh_m(self.h)
+
+    def getFarfieldHeadroom(self):
+        return lib().orc_binauraliserNF_getFarfieldHeadroom(self.h)
+
+    def getNearfieldLimit_m(self):
+        return lib().orc_binauraliserNF_getNearfieldLimit_m(self.h)
+
+    def dvf(self, nSrc):
+        """(magnitudes, phases) [nSrc][2][133] of the per-source, per-ear DVF responses."""
+        m = np.ctypeslib.as_array(lib().orc_binauraliserNF_getDVFmags(self.h), shape=(self.maxSources, 2, 133)).copy()
+        ph = np.ctypeslib.as_array(lib().orc_binauraliserNF_getDVFphases(self.h), shape=(self.maxSources, 2, 133)).copy()
+        return m[:nSrc], ph[:nSrc]
+
+
+# ------------------------------------------------------------------ DVF near-field filters
+def calcDVFShelfParams(i, rho):
+    g0, gi, fc = C.c_float(), C.c_float(), C.c_float()
+    lib().orc_calcDVFShelfParams(int(i), C.c_float(rho), C.byref(g0), C.byref(gi), C.byref(fc))
+    return g0.value, gi.value, fc.value
+
+
+def interpDVFShelfParams(theta, rho):
+    g0, gi, fc = C.c_float(), C.c_float(), C.c_float()
+    lib().orc_interpDVFShelfParams(C.c_float(theta), C.c_float(rho), C.byref(g0), C.byref(gi), C.byref(fc))
+    return g0.value, gi.value, fc.value
+
+
+def dvfShelfCoeffs(g0, gInf, fc, fs):
+    b0, b1, a1 = C.c_float(), C.c_float(), C.c_float()
+    lib().orc_dvfShelfCoeffs(C.c_float(g0), C.c_float(gInf), C.c_float(fc), C.c_float(fs), C.byref(b0), C.byref(b1), C.byref(a1))
+    return b0.value, b1.value, a1.value
+
+
+def calcDVFCoeffs(alpha, rho, fs):
+    b = np.zeros(2, np.float32); a = np.ones(2, np.float32)
+    lib().orc_calcDVFCoeffs(C.c_float(alpha), C.c_float(rho), C.c_float(fs), fptr(b), fptr(a))
+    return b, a
+
+
+def doaToIpsiInteraural(azi, elev):
+    al = np.zeros(2, np.float32); be = np.zeros(2, np.float32)
+    lib().orc_doaToIpsiInteraural(C.c_float(azi), C.c_float(elev), fptr(al), fptr(be))
+    return al, be
+
+
+def evalIIRTransferFunctionf(b, a, freqs, fs, mag2dB=0):
+    b = np.ascontiguousarray(b, np.float32); a = np.ascontiguousarray(a, np.float32); f = np.ascontiguousarray(freqs, np.float32)
+    mag = np.zeros(f.size, np.float32); ph = np.zeros(f.size, np.float32)
+    lib().orc_evalIIRTransferFunctionf(fptr(b), fptr(a), b.size, fptr(f), f.size, C.c_float(fs), mag2dB, fptr(mag), fptr(ph))
+    return mag, ph
+
+
 def _cx(a):
     return np.ascontiguousarray(a, np.complex64)
 

@@ -92,6 +92,9 @@ typedef struct {
     float* src_rot_deg;
     int nSources, new_nSources, interpMode, enableDiffEQ, enableRotation, recalcRot, useRPY, flip[3], codecReady, reinit;
     float ypr[3];
+    /* binauraliser_nf (binauraliser_nf_internal.h:140-158) */
+    int nf, curRot /* src_dirs_cur points at the rotated directions (binauraliser_nf.c:285-289) */; int* recalcDvf; float* src_dists_m; float* dvfmags; float* dvfphases; float* b_dvf; float* a_dvf;   /* [maxSrc][2][NB] x2, [maxSrc][2][2] x2 */
+    float head_radius_recip, farfield_thresh_m, farfield_headroom, nearfield_limit_m;
 } orc_bin;
 
 void orc_binauraliser_create(void** ph, int frameSize, int maxSources)
@@ -114,6 +117,7 @@ void orc_binauraliser_destroy(void** ph)
     if (p->hSTFT) orc_afSTFT_destroy(&p->hSTFT);
     free(p->set_hrirs); free(p->set_dirs); free(p->hrir_dirs_deg); free(p->itds_s); free(p->weights); free(p->hrtf_fb); free(p->hrtf_fb_mag);
     free(p->gtableComp); free(p->gtableIdx); free(p->hrtf_interp); free(p->recalc); free(p->src_dirs_deg); free(p->src_rot_deg); free(p->src_gains);
+    free(p->recalcDvf); free(p->src_dists_m); free(p->dvfmags); free(p->dvfphases); free(p->b_dvf); free(p->a_dvf);
     free(p); *ph = NULL;
 }
 void orc_binauraliser_setHRIRs(void* h, const float* hrirs, const float* dirs_deg, int N, int len, int fs)
@@ -244,10 +248,10 @@ static void rot_mtx(float yaw, float pitch, float roll, int rpy, float R[3][3]) 
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { float a = 0; for (int k = 0; k < 3; k++) a += R3[i][k] * T[k][j]; R[i][j] = a; }
 }
 
-/* binauraliser_process (binauraliser.c:191-285) */
-void orc_binauraliser_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples)
+/* binauraliser_process (binauraliser.c:191-285); with p->nf the same loop as restated by binauraliserNF_process
+ * (binauraliser_nf.c:226-367): DVF update after the HRTF interpolation and the per-source near / far choice */
+static void bin_process(orc_bin* p, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples)
 {
-    orc_bin* p = (orc_bin*)h;
     const int F = p->F, T = p->T, nS = p->nSources;
     if (nSamples != F || !p->hrtf_fb || !p->codecReady) { for (int ch = 0; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F); return; }
     float* inTD = (float*)calloc((size_t)nS * F, sizeof(float));
@@ -277,10 +281,34 @@ void orc_binauraliser_process(void* h, const float* const* inputs, float* const*
             const float* d = p->enableRotation ? &p->src_rot_deg[ch * 2] : &p->src_dirs_deg[ch * 2];
             interp_hrtfs(p, p->interpMode, d[0], d[1], &p->hrtf_interp[(size_t)ch * NB * 2]);
             p->recalc[ch] = 0;
+            if (p->nf) { p->recalcDvf[ch] = 1; p->curRot = p->enableRotation; }
+        }
+        int near = 0;
+        if (p->nf) {
+            /* binauraliser_nf.c:299-318: shelf coefficients per ear from the lateral angle and the normalised distance, then their
+             * response at the band centre frequencies */
+            if (p->recalcDvf[ch]) {
+                const float* d = p->curRot ? &p->src_rot_deg[ch * 2] : &p->src_dirs_deg[ch * 2];
+                const float rho = p->src_dists_m[ch] * p->head_radius_recip;
+                float alphaLR[2] = { 0.0f, 0.0f };
+                orc_doaToIpsiInteraural(d[0], d[1], alphaLR, NULL);
+                for (int e = 0; e < 2; e++) {
+                    float* b = &p->b_dvf[(ch * 2 + e) * 2]; float* a = &p->a_dvf[(ch * 2 + e) * 2];
+                    orc_calcDVFCoeffs(alphaLR[e], rho, (float)p->fs, b, a);
+                    orc_evalIIRTransferFunctionf(b, a, 2, p->freqVector, NB, (float)p->fs, 0, &p->dvfmags[((size_t)ch * 2 + e) * NB], &p->dvfphases[((size_t)ch * 2 + e) * NB]);
+                }
+                p->recalcDvf[ch] = 0;
+            }
+            near = p->src_dists_m[ch] < p->farfield_thresh_m;
         }
         for (int band = 0; band < NB; band++)
             for (int e = 0; e < 2; e++) {
-                const orc_cpx a = p->hrtf_interp[((size_t)ch * NB + band) * 2 + e];
+                orc_cpx a = p->hrtf_interp[((size_t)ch * NB + band) * 2 + e];
+                if (near) {     /* binauraliser_nf.c:331: cmplxf(mag, phase) * hrtf — magnitude as the real and phase as the imaginary part */
+                    const float mr = p->dvfmags[((size_t)ch * 2 + e) * NB + band], mi = p->dvfphases[((size_t)ch * 2 + e) * NB + band];
+                    const orc_cpx hh = a;
+                    a.re = mr * hh.re - mi * hh.im; a.im = mr * hh.im + mi * hh.re;
+                }
                 const orc_cpx* x = &inTF[((size_t)band * nS + ch) * T];
                 orc_cpx* y = &outTF[((size_t)band * 2 + e) * T];
                 for (int t = 0; t < T; t++) { y[t].re += a.re * x[t].re - a.im * x[t].im; y[t].im += a.re * x[t].im + a.im * x[t].re; }
@@ -295,6 +323,52 @@ void orc_binauraliser_process(void* h, const float* const* inputs, float* const*
     for (; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);
     free(inTD); free(inTF); free(outTF); free(outTD);
 }
+void orc_binauraliser_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples)
+{
+    bin_process((orc_bin*)h, inputs, outputs, nInputs, nOutputs, nSamples);
+}
+
+/* ------------------------------- binauraliser_nf ------------------------------- */
+/* binauraliserNF_create (binauraliser_nf.c:36-133): the binauraliser state plus distances and DVF responses */
+void orc_binauraliserNF_create(void** ph, int frameSize, int maxSources)
+{
+    orc_binauraliser_create(ph, frameSize, maxSources);
+    orc_bin* p = (orc_bin*)*ph;
+    p->nf = 1;
+    const float head_radius = 0.09096f;
+    p->head_radius_recip = 1.f / head_radius;
+    p->farfield_thresh_m = head_radius * 34.f;
+    p->farfield_headroom = 1.05f;
+    p->nearfield_limit_m = 0.15f;
+    p->recalcDvf = (int*)malloc(sizeof(int) * maxSources);
+    p->src_dists_m = (float*)malloc(sizeof(float) * maxSources);
+    p->dvfmags = (float*)calloc((size_t)maxSources * 2 * NB, sizeof(float));
+    p->dvfphases = (float*)calloc((size_t)maxSources * 2 * NB, sizeof(float));
+    p->b_dvf = (float*)calloc((size_t)maxSources * 4, sizeof(float));
+    p->a_dvf = (float*)calloc((size_t)maxSources * 4, sizeof(float));
+    for (int i = 0; i < maxSources; i++) {
+        p->recalcDvf[i] = 1;
+        p->src_dists_m[i] = p->farfield_thresh_m * p->farfield_headroom;      /* binauraliserNF_resetSourceDistances (binauraliser_nf_internal.c:62-70) */
+        p->a_dvf[(i * 2 + 0) * 2] = p->a_dvf[(i * 2 + 1) * 2] = 1.f;
+    }
+}
+void orc_binauraliserNF_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples)
+{
+    bin_process((orc_bin*)h, inputs, outputs, nInputs, nOutputs, nSamples);
+}
+/* binauraliserNF_setSourceDist_m (binauraliser_nf.c:372-380) */
+void orc_binauraliserNF_setSourceDist_m(void* h, int i, float d)
+{
+    orc_bin* p = (orc_bin*)h;
+    d = d > p->nearfield_limit_m ? d : p->nearfield_limit_m;
+    if (p->src_dists_m[i] != d) { p->src_dists_m[i] = d; p->recalcDvf[i] = 1; }
+}
+float orc_binauraliserNF_getSourceDist_m(void* h, int i) { return ((orc_bin*)h)->src_dists_m[i]; }
+float orc_binauraliserNF_getFarfieldThresh_m(void* h) { return ((orc_bin*)h)->farfield_thresh_m; }
+float orc_binauraliserNF_getFarfieldHeadroom(void* h) { return ((orc_bin*)h)->farfield_headroom; }
+float orc_binauraliserNF_getNearfieldLimit_m(void* h) { return ((orc_bin*)h)->nearfield_limit_m; }
+const float* orc_binauraliserNF_getDVFmags(void* h) { return ((orc_bin*)h)->dvfmags; }
+const float* orc_binauraliserNF_getDVFphases(void* h) { return ((orc_bin*)h)->dvfphases; }
 
 /* setters (binauraliser.c:289-470) */
 #define PB orc_bin* p = (orc_bin*)h

@@ -177,6 +177,27 @@ const float* orc_binauraliser_getWeights(void* h);
 const orc_cpx* orc_binauraliser_getHRTFfb(void* h);
 const orc_cpx* orc_binauraliser_getHRTFinterp(void* h);
 
+/* ---- near-field DVF filters (saf_utility_dvf.c) and first-order response (saf_utility_filters.c:609-671) ---- */
+void orc_calcDVFShelfParams(int i, float rho, float* g0, float* gInf, float* fc);
+void orc_interpDVFShelfParams(float theta, float rho, float* iG0, float* iGInf, float* iFc);
+void orc_dvfShelfCoeffs(float g0, float gInf, float fc, float fs, float* b0, float* b1, float* a1);
+void orc_calcDVFCoeffs(float alpha, float rho, float fs, float* b, float* a);
+void orc_doaToIpsiInteraural(float azimuth, float elevation, float* alphaLR, float* betaLR /* may be NULL */);
+void orc_evalIIRTransferFunctionf(const float* b_coeff, const float* a_coeff, int nCoeffs, const float* freqs, int nFreqs, float fs, int mag2dB,
+                                  float* magnitude /* may be NULL */, float* phase_rad /* may be NULL */);
+
+/* ---- binauraliser_nf (examples/src/binauraliser_nf): an orc_binauraliser handle with per-source distances; every
+ *      orc_binauraliser_* setter applies to it, process through orc_binauraliserNF_process ---- */
+void orc_binauraliserNF_create(void** ph, int frameSize, int maxSources);
+void orc_binauraliserNF_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
+void orc_binauraliserNF_setSourceDist_m(void* h, int i, float d);
+float orc_binauraliserNF_getSourceDist_m(void* h, int i);
+float orc_binauraliserNF_getFarfieldThresh_m(void* h);
+float orc_binauraliserNF_getFarfieldHeadroom(void* h);
+float orc_binauraliserNF_getNearfieldLimit_m(void* h);
+const float* orc_binauraliserNF_getDVFmags(void* h);      /* [maxSrc][2][133] */
+const float* orc_binauraliserNF_getDVFphases(void* h);    /* [maxSrc][2][133] */
+
 /* ---- powermap, PWD mode (examples/src/powermap) ---- */
 void orc_powermap_create(void** ph, int frameSize);
 void orc_powermap_destroy(void** ph);

@@ -208,6 +208,25 @@ def load():
     sig("saf_hip_binauraliser_getWeights", None, vp, fp)
     sig("saf_hip_binauraliser_getHRTFfb", None, vp, vp)
     sig("saf_hip_binauraliser_getHRTFinterp", None, vp, vp)
+    # binauraliser_nf + DVF utilities
+    sig("binauraliserNF_create", None, C.POINTER(vp))
+    sig("binauraliserNF_destroy", None, C.POINTER(vp))
+    sig("binauraliserNF_init", None, vp, ci)
+    sig("binauraliserNF_initCodec", None, vp)
+    sig("binauraliserNF_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("binauraliserNF_setSourceDist_m", None, vp, ci, cf)
+    sig("binauraliserNF_setInputConfigPreset", None, vp, ci)
+    sig("binauraliserNF_getSourceDist_m", cf, vp, ci)
+    for n in ("getFarfieldThresh_m", "getFarfieldHeadroom", "getNearfieldLimit_m"):
+        sig("binauraliserNF_" + n, cf, vp)
+    sig("saf_hip_binauraliserNF_process_dev", None, vp, vp, cll, cll, ci, vp, cll, cll, ci)
+    sig("saf_hip_binauraliserNF_getHRTFnf", None, vp, vp)
+    sig("calcDVFCoeffs", None, cf, cf, cf, fp, fp)
+    sig("interpDVFShelfParams", None, cf, cf, fp, fp, fp)
+    sig("dvfShelfCoeffs", None, cf, cf, cf, cf, fp, fp, fp)
+    sig("calcDVFShelfParams", None, ci, cf, fp, fp, fp)
+    sig("doaToIpsiInteraural", None, cf, cf, fp, fp)
+    sig("evalIIRTransferFunctionf", None, fp, fp, ci, fp, ci, cf, ci, fp, fp)
     # panner
     sig("getPvalues", None, cf, fp, ci, fp)
     sig("saf_hip_panner_setFrameSize", None, ci)

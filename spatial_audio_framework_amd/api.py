@@ -691,6 +691,91 @@ class Binauraliser:
             self.L.binauraliser_destroy(C.byref(self.h))
 
 
+class BinauraliserNF(Binauraliser):
+    """examples/include/binauraliser_nf.h: a Binauraliser whose sources carry distances (binauraliser_* calls apply to it)."""
+
+    def __init__(self, frameSize=128, maxSources=64):
+        self.L = load()
+        self.L.saf_hip_binauraliser_setFrameSize(frameSize)
+        self.L.saf_hip_binauraliser_setMaxNumSources(maxSources)
+        self.h = vp()
+        self.F = frameSize
+        self.maxSources = maxSources
+        self.L.binauraliserNF_create(C.byref(self.h))
+        self.L.saf_hip_binauraliser_setMaxNumSources(64)
+
+    def initCodec(self):
+        self.L.binauraliserNF_initCodec(self.h)
+
+    def process(self, x, nOut=2, nSamples=None):
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.binauraliserNF_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def process_dev(self, d_in, in_strides, nIn, d_out, out_strides, nFrames):
+        self.L.saf_hip_binauraliserNF_process_dev(self.h, vp(d_in), *in_strides, nIn, vp(d_out), *out_strides, nFrames)
+
+    def setSourceDist_m(self, i, d):
+        self.L.binauraliserNF_setSourceDist_m(self.h, i, C.c_float(d))
+
+    def getSourceDist_m(self, i):
+        return self.L.binauraliserNF_getSourceDist_m(self.h, i)
+
+    def setInputConfigPreset(self, preset):
+        self.L.binauraliserNF_setInputConfigPreset(self.h, preset)
+
+    def getFarfieldThresh_m(self):
+        return self.L.binauraliserNF_getFarfieldThresh_m(self.h)
+
+    def getFarfieldHeadroom(self):
+        return self.L.binauraliserNF_getFarfieldHeadroom(self.h)
+
+    def getNearfieldLimit_m(self):
+        return self.L.binauraliserNF_getNearfieldLimit_m(self.h)
+
+    def hrtf_nf(self, nSrc):
+        out = np.zeros((nSrc, 133, 2), np.complex64)
+        self.L.saf_hip_binauraliserNF_getHRTFnf(self.h, out.ctypes.data_as(vp)); return out
+
+    def __del__(self):
+        if getattr(self, "h", None) and C is not None:
+            self.L.binauraliserNF_destroy(C.byref(self.h))
+
+
+# DVF near-field filters (saf_utility_dvf.h) and evalIIRTransferFunctionf (saf_utility_filters.h); host functions
+def calcDVFShelfParams(i, rho):
+    o = np.zeros(3, np.float32)
+    load().calcDVFShelfParams(int(i), C.c_float(rho), _f(o[0:1]), _f(o[1:2]), _f(o[2:3])); return tuple(o)
+
+
+def interpDVFShelfParams(theta, rho):
+    o = np.zeros(3, np.float32)
+    load().interpDVFShelfParams(C.c_float(theta), C.c_float(rho), _f(o[0:1]), _f(o[1:2]), _f(o[2:3])); return tuple(o)
+
+
+def dvfShelfCoeffs(g0, gInf, fc, fs):
+    o = np.zeros(3, np.float32)
+    load().dvfShelfCoeffs(C.c_float(g0), C.c_float(gInf), C.c_float(fc), C.c_float(fs), _f(o[0:1]), _f(o[1:2]), _f(o[2:3])); return tuple(o)
+
+
+def calcDVFCoeffs(alpha, rho, fs):
+    b = np.zeros(2, np.float32); a = np.ones(2, np.float32)
+    load().calcDVFCoeffs(C.c_float(alpha), C.c_float(rho), C.c_float(fs), _f(b), _f(a)); return b, a
+
+
+def doaToIpsiInteraural(azi, elev):
+    al = np.zeros(2, np.float32); be = np.zeros(2, np.float32)
+    load().doaToIpsiInteraural(C.c_float(azi), C.c_float(elev), _f(al), _f(be)); return al, be
+
+
+def evalIIRTransferFunctionf(b, a, freqs, fs, mag2dB=0):
+    b = np.ascontiguousarray(b, np.float32); a = np.ascontiguousarray(a, np.float32); f = np.ascontiguousarray(freqs, np.float32)
+    mag = np.zeros(f.size, np.float32); ph = np.zeros(f.size, np.float32)
+    load().evalIIRTransferFunctionf(_f(b), _f(a), b.size, _f(f), f.size, C.c_float(fs), mag2dB, _f(mag), _f(ph)); return mag, ph
+
+
 class BinauraliserBatch:
     """saf_hip_binauraliser_batch_*: nInst initialised handles, device-resident blocks."""
 

@@ -5,6 +5,9 @@
  *                        VBAP grid over the HRIR directions -> 3 gains + 3 HRIR indices -> either the complex
  *                        triangular interpolation (INTERP_TRI) or magnitude + ITD interpolation with the interaural
  *                        phase re-introduced below 1.5 kHz (INTERP_TRI_PS).  One workgroup per source that moved.
+ *   dvf_scale_kernel     binauraliser_nf (binauraliser_nf.c:299-338): response of each near source's two first-order DVF
+ *                        shelves at the 133 band centres, multiplied onto the interpolated HRTF (the reference's product
+ *                        (magnitude + i phase) * hrtf, kept as it is); far sources pass through.
  *   binaural_mac_kernel  the band MAC of binauraliser_process (binauraliser.c:252-268): per band a [2 x nSrc] x
  *                        [nSrc x T] complex product.  Spectra rows [src][hop] are read exactly once; the source sum is
  *                        split over the thread groups of a workgroup and folded through LDS.
@@ -65,6 +68,42 @@ void launch_hrtf_interp(const HrtfInterpLaunch& l)
     InterpArgs a; a.l = l;
     KernelTimer kt("hrtf_interp");
     hipLaunchKernelGGL(hrtf_interp_kernel, dim3(l.nSrc, l.nInst > 0 ? l.nInst : 1), dim3(192), 0, stream(), a);
+    HIP_CHECK(hipGetLastError());
+}
+
+struct DvfArgs { DvfScaleLaunch l; };
+
+/* grid (nSrc, nInst), one thread per band */
+__global__ __launch_bounds__(192) void dvf_scale_kernel(DvfArgs a)
+{
+    const DvfScaleLaunch& l = a.l;
+    const int src = blockIdx.y * l.srcStride + blockIdx.x, band = threadIdx.x;
+    if (band >= SAF_NBANDS) return;
+    const float2* hin = l.hrtf_interp + ((long long)src * SAF_NBANDS + band) * 2;
+    float2* hout = l.hrtf_nf + ((long long)src * SAF_NBANDS + band) * 2;
+    const float w = l.freq[band] * (float)(-2.0 * SAF_PI / l.fs);      /* z^-1 = e^{-jw} */
+    float sx, cx;
+    sincosf(w, &sx, &cx);
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const float4 k = *reinterpret_cast<const float4*>(l.coef + ((long long)src * 2 + e) * 4);    /* b0, b1, a1, near */
+        const float2 h = hin[e];
+        if (k.w == 0.0f) { hout[e] = h; continue; }
+        const float nr = k.x + k.y * cx, ni = k.y * sx, dr = 1.0f + k.z * cx, di = k.z * sx;
+        const double inv = 1.0 / (double)(dr * dr + di * di + 2.23e-7f);
+        const float mag = (float)sqrt((double)(nr * nr + ni * ni) * inv);
+        const float hr = (float)((double)(nr * dr + ni * di) * inv), hi = (float)((double)(ni * dr - nr * di) * inv);
+        const float ph = (float)atan2((double)hi, (double)hr);
+        hout[e] = make_float2(mag * h.x - ph * h.y, mag * h.y + ph * h.x);
+    }
+}
+
+void launch_dvf_scale(const DvfScaleLaunch& l)
+{
+    if (l.nSrc <= 0) return;
+    DvfArgs a; a.l = l;
+    KernelTimer kt("dvf_scale");
+    hipLaunchKernelGGL(dvf_scale_kernel, dim3(l.nSrc, l.nInst > 0 ? l.nInst : 1), dim3(192), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 

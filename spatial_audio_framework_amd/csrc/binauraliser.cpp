@@ -13,6 +13,12 @@
  * file I/O outside the hot path, so the set in use is the one installed with saf_hip_setDefaultHRIRs.
  * The reference caps the sources at MAX_NUM_INPUTS = 64 (_common.h:231); saf_hip_binauraliser_setMaxNumSources
  * raises that cap for handles created afterwards (BASELINE configs[2] renders 256 sources).
+ *
+ * binauraliser_nf (examples/include/binauraliser_nf.h:76-194, examples/src/binauraliser_nf): the same operator with a
+ * distance per source.  A handle from binauraliserNF_create is a binauraliser handle (every binauraliser_* call applies,
+ * as in the reference, whose NF struct begins with the binauraliser members); binauraliserNF_process adds one step: for
+ * each moved source the two DVF shelves (dvf_host.cpp) are re-derived on the host and one small kernel multiplies their
+ * band responses onto the interpolated HRTFs of the near sources before the band MAC.
  */
 #include "saf_hip_common.h"
 #include "../../include/saf_hip.h"
@@ -20,6 +26,7 @@
 #include "design_host.h"
 #include "hrir_host.h"
 #include "presets.h"
+#include "dvf_host.h"
 #include <thread>
 #include <chrono>
 
@@ -67,7 +74,41 @@ struct Binauraliser {
     std::vector<float> shadowGains;
     PinBuf<float> h_in, h_out;
     DevBuf<float> d_in, d_out;
+    /* binauraliser_nf (binauraliser_nf_internal.h:140-158) */
+    bool nf = false;
+    int curRot = 0;                         /* src_dirs_cur points at the rotated directions (binauraliser_nf.c:285-289) */
+    std::vector<int> recalc_dvfCoeffFLAG;
+    std::vector<float> src_dists_m, dvfCoef, dvfCoefOnDevice;   /* [maxSrc], [maxSrc][2][4] = b0 b1 a1 near */
+    float head_radius = 0.09096f, head_radius_recip = 0.0f, farfield_thresh_m = 0.0f, farfield_headroom = 1.05f, nearfield_limit_m = 0.15f;
+    DevBuf<float2> d_hrtf_nf;
+    DevBuf<float> d_dvfCoef;
+    PinBuf<float> stDvf;
 };
+
+/* binauraliserNF_process (binauraliser_nf.c:291-318): shelf coefficients of the sources whose direction or distance changed.
+ * Fills p->dvfCoef; returns true when the device copy is stale. */
+static bool nf_refresh_coeffs(Binauraliser* p)
+{
+    const int nS = p->nSources;
+    const std::vector<float>& dirs = p->curRot ? p->src_dirs_rot_deg : p->src_dirs_deg;
+    for (int ch = 0; ch < nS; ch++) {
+        float* k = &p->dvfCoef[(size_t)ch * 8];
+        if (p->recalc_dvfCoeffFLAG[ch]) {
+            const float rho = p->src_dists_m[ch] * p->head_radius_recip;
+            float alphaLR[2] = { 0.0f, 0.0f };
+            dvf_lateral_angles(dirs[ch * 2], dirs[ch * 2 + 1], alphaLR, nullptr);
+            for (int e = 0; e < 2; e++) {
+                float b[2], a[2] = { 1.0f, 0.0f };
+                dvf_coeffs(alphaLR[e], rho, (float)p->fs, b, a);
+                k[e * 4 + 0] = b[0]; k[e * 4 + 1] = b[1]; k[e * 4 + 2] = a[1];
+            }
+            p->recalc_dvfCoeffFLAG[ch] = 0;
+        }
+        const float near = p->src_dists_m[ch] < p->farfield_thresh_m ? 1.0f : 0.0f;       /* binauraliser_nf.c:321 */
+        k[3] = k[7] = near;
+    }
+    return p->dvfCoefOnDevice.size() != p->dvfCoef.size() || memcmp(p->dvfCoefOnDevice.data(), p->dvfCoef.data(), sizeof(float) * (size_t)nS * 8) != 0;
+}
 
 static void set_codec_status(Binauraliser* p, CODEC_STATUS s)     /* binauraliser_internal.c:32-44 */
 {
@@ -171,7 +212,7 @@ static void rotate_sources(Binauraliser* p)
 
 /* the block path for nFrames consecutive blocks of device-resident samples */
 static void process_dev(Binauraliser* p, const float* d_in, long long in_frame, long long in_ch, int nIn,
-                        float* d_out, long long out_frame, long long out_ch, int nOut, int nFrames)
+                        float* d_out, long long out_frame, long long out_ch, int nOut, int nFrames, bool nearField = false)
 {
     const int nS = p->nSources, T = p->T, H = nFrames * T;
     if (H > p->Hmax) {
@@ -210,7 +251,11 @@ static void process_dev(Binauraliser* p, const float* d_in, long long in_frame, 
         HIP_CHECK(hipStreamSynchronize(stream()));
         const std::vector<float>& dirs = p->enableRotation ? p->src_dirs_rot_deg : p->src_dirs_deg;
         memcpy(p->stF.p, dirs.data(), sizeof(float) * 2 * nS);
-        for (int ch = 0; ch < nS; ch++) { p->stI.p[ch] = p->recalc_hrtf_interpFLAG[ch]; p->recalc_hrtf_interpFLAG[ch] = 0; }
+        for (int ch = 0; ch < nS; ch++) {
+            p->stI.p[ch] = p->recalc_hrtf_interpFLAG[ch];
+            if (p->nf && p->recalc_hrtf_interpFLAG[ch]) { p->recalc_dvfCoeffFLAG[ch] = 1; p->curRot = p->enableRotation; p->dvfCoefOnDevice.clear(); }
+            p->recalc_hrtf_interpFLAG[ch] = 0;
+        }
         HIP_CHECK(hipMemcpyAsync(p->d_dirs.p, p->stF.p, sizeof(float) * 2 * nS, hipMemcpyHostToDevice, stream()));
         HIP_CHECK(hipMemcpyAsync(p->d_recalc.p, p->stI.p, sizeof(int) * nS, hipMemcpyHostToDevice, stream()));
         memcpy(p->stF.p + 2 * p->maxSrc, p->freqVector, sizeof(float) * SAF_NBANDS);
@@ -222,9 +267,22 @@ static void process_dev(Binauraliser* p, const float* d_in, long long in_frame, 
         l.aziRes = p->hrtf_vbapTableRes[0]; l.elevRes = p->hrtf_vbapTableRes[1];
         launch_hrtf_interp(l);
     }
+    const bool useNF = p->nf && nearField;
+    if (useNF && nf_refresh_coeffs(p)) {
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        memcpy(p->stDvf.p, p->dvfCoef.data(), sizeof(float) * (size_t)nS * 8);
+        memcpy(p->stDvf.p + (size_t)p->maxSrc * 8, p->freqVector, sizeof(float) * SAF_NBANDS);
+        HIP_CHECK(hipMemcpyAsync(p->d_dvfCoef.p, p->stDvf.p, sizeof(float) * (size_t)nS * 8, hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(p->d_freq.p, p->stDvf.p + (size_t)p->maxSrc * 8, sizeof(float) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
+        p->dvfCoefOnDevice = p->dvfCoef;
+        DvfScaleLaunch d{};
+        d.hrtf_interp = p->d_hrtf_interp.p; d.coef = p->d_dvfCoef.p; d.freq = p->d_freq.p; d.hrtf_nf = p->d_hrtf_nf.p;
+        d.fs = (float)p->fs; d.nSrc = nS;
+        launch_dvf_scale(d);
+    }
     BinMacLaunch m{};
     m.X = p->X.p; m.x_band = a.out_band; m.x_ch = a.out_ch;
-    m.h = p->d_hrtf_interp.p;
+    m.h = useNF ? p->d_hrtf_nf.p : p->d_hrtf_interp.p;
     m.Y = p->Y.p; m.y_band = (long long)2 * p->Hmax; m.y_ch = p->Hmax;
     m.nSrc = nS; m.H = H; m.scale = 1.0f / sqrtf((float)nS);
     launch_binaural_mac(m);
@@ -250,6 +308,8 @@ struct BinBatch {
     DevBuf<int> recalc;
     PinBuf<float> stD, stG; PinBuf<int> stR;
     std::vector<float> shadowGains;
+    bool nf = false;                        /* binauraliser_nf instances: DVF-scaled HRTFs feed the MAC */
+    DevBuf<float2> hrtfNf; DevBuf<float> dvfCoef; PinBuf<float> stK;
 
     void create(Binauraliser* const* h, int n, int maxFrames_)
     {
@@ -262,7 +322,10 @@ struct BinBatch {
             if (p->F != F || p->maxSrc != maxSrc || p->nSources != nS) SAF_FATAL("binauraliser batch: all instances must share block size, source cap and source count");
             if (p->N_hrir_dirs != p0->N_hrir_dirs || p->enableHRIRsDiffuseEQ != p0->enableHRIRsDiffuseEQ || p->fs != p0->fs)
                 SAF_FATAL("binauraliser batch: all instances must share the HRIR set, the diffuse-field EQ flag and the sample rate");
+            if (p->nf != p0->nf) SAF_FATAL("binauraliser batch: binauraliser and binauraliser_nf handles cannot be mixed");
         }
+        nf = p0->nf;
+        if (nf) { hrtfNf.alloc((size_t)n * maxSrc * SAF_NBANDS * 2); dvfCoef.alloc((size_t)n * maxSrc * 8); stK.ensure((size_t)n * maxSrc * 8); }
         Hmax = (T * maxFrames + 15) & ~15;
         st.create(nInst, nS, 2);
         X.alloc((size_t)nInst * SAF_NBANDS * maxSrc * Hmax, true);
@@ -314,7 +377,11 @@ struct BinBatch {
                 Binauraliser* p = inst[i];
                 const std::vector<float>& d = p->enableRotation ? p->src_dirs_rot_deg : p->src_dirs_deg;
                 memcpy(stD.p + (size_t)i * maxSrc * 2, d.data(), sizeof(float) * 2 * maxSrc);
-                for (int ch = 0; ch < maxSrc; ch++) { stR.p[(size_t)i * maxSrc + ch] = ch < nS ? p->recalc_hrtf_interpFLAG[ch] : 0; if (ch < nS) p->recalc_hrtf_interpFLAG[ch] = 0; }
+                for (int ch = 0; ch < maxSrc; ch++) {
+                    stR.p[(size_t)i * maxSrc + ch] = ch < nS ? p->recalc_hrtf_interpFLAG[ch] : 0;
+                    if (ch < nS && p->nf && p->recalc_hrtf_interpFLAG[ch]) { p->recalc_dvfCoeffFLAG[ch] = 1; p->curRot = p->enableRotation; p->dvfCoefOnDevice.clear(); }
+                    if (ch < nS) p->recalc_hrtf_interpFLAG[ch] = 0;
+                }
             }
             memcpy(stD.p + (size_t)nInst * maxSrc * 2, p0->freqVector, sizeof(float) * SAF_NBANDS);
             HIP_CHECK(hipMemcpyAsync(dirs.p, stD.p, sizeof(float) * (size_t)nInst * maxSrc * 2, hipMemcpyHostToDevice, stream()));
@@ -328,9 +395,25 @@ struct BinBatch {
             l.nInst = nInst; l.srcStride = maxSrc;
             launch_hrtf_interp(l);
         }
+        if (nf) {
+            bool stale = false;
+            for (int i = 0; i < nInst; i++) stale = nf_refresh_coeffs(inst[i]) || stale;
+            if (stale) {
+                HIP_CHECK(hipStreamSynchronize(stream()));
+                for (int i = 0; i < nInst; i++) {
+                    memcpy(stK.p + (size_t)i * maxSrc * 8, inst[i]->dvfCoef.data(), sizeof(float) * (size_t)maxSrc * 8);
+                    inst[i]->dvfCoefOnDevice = inst[i]->dvfCoef;
+                }
+                HIP_CHECK(hipMemcpyAsync(dvfCoef.p, stK.p, sizeof(float) * (size_t)nInst * maxSrc * 8, hipMemcpyHostToDevice, stream()));
+                DvfScaleLaunch d{};
+                d.hrtf_interp = hrtfInterp.p; d.coef = dvfCoef.p; d.freq = p0->d_freq.p; d.hrtf_nf = hrtfNf.p;
+                d.fs = (float)p0->fs; d.nSrc = nS; d.nInst = nInst; d.srcStride = maxSrc;
+                launch_dvf_scale(d);
+            }
+        }
         BinMacLaunch m{};
         m.X = X.p; m.x_inst = a.out_inst; m.x_band = a.out_band; m.x_ch = a.out_ch;
-        m.h = hrtfInterp.p; m.h_inst = (long long)maxSrc * SAF_NBANDS * 2;
+        m.h = nf ? hrtfNf.p : hrtfInterp.p; m.h_inst = (long long)maxSrc * SAF_NBANDS * 2;
         m.Y = Y.p; m.y_inst = (long long)SAF_NBANDS * 2 * Hmax; m.y_band = (long long)2 * Hmax; m.y_ch = Hmax;
         m.nSrc = nS; m.H = H; m.scale = 1.0f / sqrtf((float)nS); m.nInst = nInst;
         launch_binaural_mac(m);
@@ -416,6 +499,7 @@ void binauraliser_initCodec(void* const hBin)
         p->d_hrtf_interp.alloc((size_t)p->maxSrc * SAF_NBANDS * 2);
         p->d_dirs.alloc((size_t)p->maxSrc * 2); p->d_recalc.alloc(p->maxSrc); p->d_gains.alloc(p->maxSrc); p->d_freq.alloc(SAF_NBANDS);
         p->stF.ensure((size_t)2 * p->maxSrc + SAF_NBANDS); p->stI.ensure(p->maxSrc);
+        if (p->nf) { p->d_hrtf_nf.alloc((size_t)p->maxSrc * SAF_NBANDS * 2); p->d_dvfCoef.alloc((size_t)p->maxSrc * 8); p->stDvf.ensure((size_t)p->maxSrc * 8 + SAF_NBANDS); }
         p->haveSTFT = true;
     } else if (p->new_nSources != p->nSources) { p->st.channelChange(p->new_nSources, 2); p->st.clear(); }
     p->nSources = p->new_nSources;
@@ -424,9 +508,8 @@ void binauraliser_initCodec(void* const hBin)
     p->codecStatus = CODEC_STATUS_INITIALISED;
 }
 
-void binauraliser_process(void* const hBin, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples)
+static void process_host(Binauraliser* p, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples, bool nearField)
 {
-    Binauraliser* p = (Binauraliser*)hBin;
     const int F = p->F, nS = p->nSources;
     if (nSamples == F && !p->hrtf_fb.empty() && p->codecStatus == CODEC_STATUS_INITIALISED) {
         p->procStatus = PROC_STATUS_ONGOING;
@@ -437,11 +520,11 @@ void binauraliser_process(void* const hBin, const float* const* inputs, float** 
         DevBuf<float>& o = p->d_out;
         if (o.n < (size_t)2 * F) o.alloc((size_t)2 * F, false);
         /* always synthesise both ears; the copy-out below honours nOutputs (binauraliser.c:274-277) */
-        if (zero_copy_io()) process_dev(p, p->h_in.p, 0, F, nIn, p->h_out.p, 0, F, 2, 1);                 /* kernels on the pinned blocks */
+        if (zero_copy_io()) process_dev(p, p->h_in.p, 0, F, nIn, p->h_out.p, 0, F, 2, 1, nearField);                 /* kernels on the pinned blocks */
         else {
             if (nIn) HIP_CHECK(hipMemcpyAsync(p->d_in.p, p->h_in.p, sizeof(float) * (size_t)nIn * F, hipMemcpyHostToDevice, stream()));
             float* d_o = o.p;
-            process_dev(p, p->d_in.p, 0, F, nIn, d_o, 0, F, 2, 1);
+            process_dev(p, p->d_in.p, 0, F, nIn, d_o, 0, F, 2, 1, nearField);
             HIP_CHECK(hipMemcpyAsync(p->h_out.p, d_o, sizeof(float) * (size_t)2 * F, hipMemcpyDeviceToHost, stream()));
         }
         HIP_CHECK(hipStreamSynchronize(stream()));
@@ -451,6 +534,11 @@ void binauraliser_process(void* const hBin, const float* const* inputs, float** 
     } else
         for (int ch = 0; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);      /* binauraliser.c:279-282 */
     p->procStatus = PROC_STATUS_NOT_ONGOING;
+}
+
+void binauraliser_process(void* const hBin, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples)
+{
+    process_host((Binauraliser*)hBin, inputs, outputs, nInputs, nOutputs, nSamples, false);
 }
 
 void saf_hip_binauraliser_process_dev(void* const hBin, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
@@ -559,6 +647,68 @@ void saf_hip_binauraliser_getHRTFinterp(void* const hBin, float_complex* hrtf_in
     PBN;
     HIP_CHECK(hipStreamSynchronize(stream()));
     HIP_CHECK(hipMemcpy((void*)hrtf_interp, p->d_hrtf_interp.p, sizeof(float2) * (size_t)p->nSources * SAF_NBANDS * 2, hipMemcpyDeviceToHost));
+}
+
+/* ------------------------------- binauraliser_nf (examples/include/binauraliser_nf.h:76-194) ------------------------------- */
+static void nf_reset_distances(Binauraliser* p)         /* binauraliserNF_resetSourceDistances (binauraliser_nf_internal.c:62-70) */
+{
+    for (int i = 0; i < p->maxSrc; i++) p->src_dists_m[i] = p->farfield_thresh_m * p->farfield_headroom;
+}
+void binauraliserNF_create(void** const phBin)
+{
+    binauraliser_create(phBin);
+    Binauraliser* p = (Binauraliser*)*phBin;
+    p->nf = true;
+    /* binauraliser_nf.c:64-80: head radius of the DVF model, far field from rho = 34 (about 3.09 m), stable down to 0.15 m */
+    p->head_radius_recip = 1.f / p->head_radius;
+    p->farfield_thresh_m = p->head_radius * 34.f;
+    p->src_dists_m.assign(p->maxSrc, 0.0f);
+    nf_reset_distances(p);
+    p->recalc_dvfCoeffFLAG.assign(p->maxSrc, 1);
+    p->dvfCoef.assign((size_t)p->maxSrc * 8, 0.0f);
+}
+void binauraliserNF_destroy(void** const phBin) { binauraliser_destroy(phBin); }
+void binauraliserNF_init(void* const hBin, int sampleRate) { binauraliser_init(hBin, sampleRate); }       /* binauraliser_nf.c:172-178 */
+void binauraliserNF_initCodec(void* const hBin) { binauraliser_initCodec(hBin); }                         /* binauraliser_nf.c:187-224: the same steps with the 2-channel synthesis */
+void binauraliserNF_process(void* const hBin, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples)
+{
+    Binauraliser* p = (Binauraliser*)hBin;
+    if (!p->nf) SAF_FATAL("binauraliserNF_process on a handle that was not made by binauraliserNF_create");
+    process_host(p, inputs, outputs, nInputs, nOutputs, nSamples, true);
+}
+void saf_hip_binauraliserNF_process_dev(void* const hBin, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
+                                        float* d_out, long long out_frame_stride, long long out_ch_stride, int nFrames)
+{
+    Binauraliser* p = (Binauraliser*)hBin;
+    if (!p->nf) SAF_FATAL("binauraliserNF process_dev on a handle that was not made by binauraliserNF_create");
+    if (p->hrtf_fb.empty() || p->codecStatus != CODEC_STATUS_INITIALISED) SAF_FATAL("binauraliserNF: process_dev on a handle that is not initialised (call binauraliserNF_initCodec)");
+    p->procStatus = PROC_STATUS_ONGOING;
+    process_dev(p, d_in, in_frame_stride, in_ch_stride, nInputs < 0 ? 0 : nInputs, d_out, out_frame_stride, out_ch_stride, 2, nFrames, true);
+    p->procStatus = PROC_STATUS_NOT_ONGOING;
+}
+void binauraliserNF_setSourceDist_m(void* const hBin, int index, float newDist_m)       /* binauraliser_nf.c:372-380 */
+{
+    PBN;
+    newDist_m = newDist_m > p->nearfield_limit_m ? newDist_m : p->nearfield_limit_m;
+    if (p->src_dists_m[index] != newDist_m) { p->src_dists_m[index] = newDist_m; p->recalc_dvfCoeffFLAG[index] = 1; }
+}
+void binauraliserNF_setInputConfigPreset(void* const hBin, int newPresetID)               /* binauraliser_nf.c:382-398: presets put the sources back in the far field */
+{
+    PBN;
+    binauraliser_setInputConfigPreset(hBin, newPresetID);
+    nf_reset_distances(p);
+    for (int ch = 0; ch < p->maxSrc; ch++) p->recalc_dvfCoeffFLAG[ch] = 1;
+}
+float binauraliserNF_getSourceDist_m(void* const hBin, int index) { PBN; return p->src_dists_m[index]; }
+float binauraliserNF_getFarfieldThresh_m(void* const hBin) { PBN; return p->farfield_thresh_m; }
+float binauraliserNF_getFarfieldHeadroom(void* const hBin) { PBN; return p->farfield_headroom; }
+float binauraliserNF_getNearfieldLimit_m(void* const hBin) { PBN; return p->nearfield_limit_m; }
+/* read-back for parity checks: the filters the band MAC applies, [nSources][133][2] (HRTF x DVF for near sources) */
+void saf_hip_binauraliserNF_getHRTFnf(void* const hBin, float_complex* hrtf_nf)
+{
+    PBN;
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    HIP_CHECK(hipMemcpy((void*)hrtf_nf, p->d_hrtf_nf.p, sizeof(float2) * (size_t)p->nSources * SAF_NBANDS * 2, hipMemcpyDeviceToHost));
 }
 
 void* saf_hip_binauraliser_batch_create(void* const* hBins, int nInst, int maxFramesPerCall)

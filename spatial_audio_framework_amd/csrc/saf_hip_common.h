@@ -242,6 +242,16 @@ struct HrtfInterpLaunch {       /* binauraliser_interpHRTFs (binauraliser_intern
     int nInst = 1, srcStride = 0;   /* batches: instance i uses srcDirs / recalc / hrtf_interp entries i*srcStride + src */
 };
 void launch_hrtf_interp(const HrtfInterpLaunch& l);
+struct DvfScaleLaunch {         /* binauraliser_nf.c:299-338: per source and ear the response of the first-order DVF shelf at the band centres
+                                 * (evalIIRTransferFunctionf, saf_utility_filters.c:609-671) combined with the interpolated HRTF */
+    const float2* hrtf_interp;  /* [nInst * srcStride][133][2] */
+    const float* coef;          /* [nInst * srcStride][2 ears][4]: b0, b1, a1, near-field flag (0: far field, HRTF passes unchanged) */
+    const float* freq;          /* [133] */
+    float2* hrtf_nf;            /* out, layout of hrtf_interp */
+    float fs;
+    int nSrc, nInst = 1, srcStride = 0;
+};
+void launch_dvf_scale(const DvfScaleLaunch& l);
 struct BinMacLaunch {           /* out[band][ear][t] = scale * sum_src h[src][band][ear] * X[band][src][t]  (binauraliser.c:252-268) */
     const float2* X; long long x_band, x_ch;
     const float2* h;

@@ -65,6 +65,7 @@ def generate(O):
     out["rotator_small"] = {"out": rotator_scenario(O.Rotator)}
     out["beamformer_small"] = {"out": beamformer_scenario(O.Beamformer)}
     out["ambi_drc_small"] = {"out": ambi_drc_scenario(O.AmbiDrc)}
+    out["binauraliser_nf_small"] = {"out": binauraliser_nf_scenario(O.BinauraliserNF)}
     return out
 
 
@@ -79,6 +80,27 @@ def ambi_bin_scenario(cls, F=128, nB=20):
         if b == 10:
             a.setEnableRotation(1); a.setYaw(45.0); a.setPitch(10.0)
         ys.append(a.process(x[:, b * F:(b + 1) * F], 2))
+    return np.concatenate(ys, 1)
+
+
+def binauraliser_nf_scenario(cls, F=128, nB=20):
+    """8 sources between 0.15 and 3.5 m, source 1 brought from 2 m to 0.2 m at block 6, source 0 sent to the far field at block 9,
+    head rotation from block 12 on"""
+    h, d = synth_hrirs()
+    b = cls(F, 64)
+    b.setHRIRs(h, d, 48000); b.init(48000); b.setNumSources(8); b.initCodec()
+    for s in range(8):
+        b.setSourceAzi_deg(s, float(45 * s - 170)); b.setSourceElev_deg(s, float(20 * (s % 4) - 30)); b.setSourceDist_m(s, float(0.15 + 0.48 * s))
+    x = frames(909, 8, nB * F)
+    ys = []
+    for blk in range(nB):
+        if blk == 6:
+            b.setSourceDist_m(1, 0.2)
+        if blk == 9:
+            b.setSourceDist_m(0, 6.0)
+        if blk == 12:
+            b.setEnableRotation(1); b.setYaw(60.0); b.setRoll(-20.0)
+        ys.append(b.process(x[:, blk * F:(blk + 1) * F], 2))
     return np.concatenate(ys, 1)
 
 

@@ -56,3 +56,4 @@ def test_golden_rotator_beamformer_ambi_drc(saf):
     assert relrms(mg.rotator_scenario(saf.Rotator), np.load(GOLD / "rotator_small.npz")["out"]) < 2e-6
     assert relrms(mg.beamformer_scenario(saf.Beamformer), np.load(GOLD / "beamformer_small.npz")["out"]) < 2e-6
     assert relrms(mg.ambi_drc_scenario(saf.AmbiDrc), np.load(GOLD / "ambi_drc_small.npz")["out"]) < TOL
+    assert relrms(mg.binauraliser_nf_scenario(saf.BinauraliserNF), np.load(GOLD / "binauraliser_nf_small.npz")["out"]) < TOL

@@ -89,3 +89,42 @@ def test_preset_tables_match_oracle_tables(saf, orc):
         t = orc.table(tab)
         got = np.array([[d.getLoudspeakerAzi_deg(i), d.getLoudspeakerElev_deg(i)] for i in range(n)], np.float32)
         assert np.array_equal(got, t)
+
+
+def test_dvf_host_functions_known_answers(saf, orc):
+    """The library's host DVF functions (include/saf_hip.h: calcDVFShelfParams, interpDVFShelfParams, dvfShelfCoeffs, calcDVFCoeffs,
+    doaToIpsiInteraural, evalIIRTransferFunctionf — no GPU involved) against the reference's own known answers
+    (test__dvf_* and the DVF cases of test__evalIIRTransferFunction, test/src/test__utilities_module.c:1114-1190, 1304-1440) and
+    against the CPU restatement."""
+    import json
+    from pathlib import Path
+    import numpy as np
+    k = json.loads((Path(__file__).parent / "golden" / "dvf_known_answers.json").read_text())
+    sp = k["shelf_params"]
+    for ri, rho in enumerate(sp["rho"]):
+        for ti in range(19):
+            g0, gi, fc = saf.calcDVFShelfParams(ti, rho)
+            assert abs(g0 - sp["g0"][ri][ti]) <= sp["tol"] and abs(gi - sp["gInf"][ri][ti]) <= sp["tol"] and abs(fc - sp["fc"][ri][ti]) <= sp["tol_fc"]
+            assert (g0, gi, fc) == tuple(np.float32(v) for v in orc.calcDVFShelfParams(ti, rho))
+    ip, sc = k["interp_params"], k["shelf_coeffs"]
+    for ri, rho in enumerate(ip["rho"]):
+        for ti, th in enumerate(ip["theta"]):
+            g0, gi, fc = saf.interpDVFShelfParams(th, rho)
+            assert abs(g0 - ip["iG0"][ri][ti]) <= ip["tol"] and abs(gi - ip["iGInf"][ri][ti]) <= ip["tol"] and abs(fc - ip["iFc"][ri][ti]) <= ip["tol_fc"]
+            b0, b1, a1 = saf.dvfShelfCoeffs(float(g0), float(gi), float(fc), sc["fs"])
+            assert abs(b0 - sc["b0"][ri][ti]) <= sc["tol"] and abs(b1 - sc["b1"][ri][ti]) <= sc["tol"] and abs(a1 - sc["a1"][ri][ti]) <= sc["tol"]
+            b, a = saf.calcDVFCoeffs(th, rho, sc["fs"])
+            bo, ao = orc.calcDVFCoeffs(th, rho, sc["fs"])
+            assert np.array_equal(b, bo) and np.array_equal(a, ao)
+    ii = k["iir"]
+    for t in range(12):
+        mag, ph = saf.evalIIRTransferFunctionf(ii["b"][t], ii["a"][t], ii["freqs"], ii["fs"])
+        ref_db = 20 * np.log10(np.array(ii["mags"][t]))
+        assert np.all(np.abs(20 * np.log10(mag) - ref_db) <= ii["tol"]["mag_dB"] + ii["tol"]["errScale"] * np.abs(ref_db))
+        assert np.all(np.abs(ph - np.array(ii["phases"][t])) <= ii["tol"]["phase"])
+        mo, po = orc.evalIIRTransferFunctionf(ii["b"][t], ii["a"][t], ii["freqs"], ii["fs"])
+        assert np.abs(mag - mo).max() < 1e-6 * mo.max() and np.abs(ph - po).max() < 1e-6
+    for az, el in ((30.0, 10.0), (-120.0, 45.0), (179.0, -80.0), (0.0, 0.0)):
+        al, be = saf.doaToIpsiInteraural(az, el)
+        alo, beo = orc.doaToIpsiInteraural(az, el)
+        assert np.abs(al - alo).max() < 1e-4 and np.abs(be - beo).max() < 1e-4

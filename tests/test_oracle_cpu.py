@@ -633,3 +633,66 @@ def test_beamformer_weights_closed_forms():
         wh = O.rotateAxisCoeffsReal(N, O.beamWeights(2, N), np.pi / 2 - np.radians(20.0), np.radians(30.0))
         rh = wh @ Yn3d
         assert abs(rh[0] - np.sqrt(4 * np.pi)) < 1e-5 and np.abs(rh).max() <= rh[0] + 1e-6    # on-axis gain sqrt(4 pi) (N3D signals carry sqrt(4 pi) Y), maximum there
+
+
+# ------------------------------------------------------------------ DVF near-field filters (binauraliser_nf)
+DVF = json.loads((Path(__file__).parent / "golden" / "dvf_known_answers.json").read_text())
+
+
+def test_dvf_calcDVFShelfParams_known_answers():
+    """test__dvf_calcDVFShelfParams (test__utilities_module.c:1304-1345): shelf gains and cut-off at the 19 table angles, 5 distances."""
+    from oracle import oracle as O
+    k = DVF["shelf_params"]
+    for ri, rho in enumerate(k["rho"]):
+        for ti in range(19):
+            g0, gi, fc = O.calcDVFShelfParams(ti, rho)
+            assert abs(g0 - k["g0"][ri][ti]) <= k["tol"] and abs(gi - k["gInf"][ri][ti]) <= k["tol"] and abs(fc - k["fc"][ri][ti]) <= k["tol_fc"]
+
+
+def test_dvf_interpDVFShelfParams_known_answers():
+    """test__dvf_interpDVFShelfParams (test__utilities_module.c:1348-1396)."""
+    from oracle import oracle as O
+    k = DVF["interp_params"]
+    for ri, rho in enumerate(k["rho"]):
+        for ti, th in enumerate(k["theta"]):
+            g0, gi, fc = O.interpDVFShelfParams(th, rho)
+            assert abs(g0 - k["iG0"][ri][ti]) <= k["tol"] and abs(gi - k["iGInf"][ri][ti]) <= k["tol"] and abs(fc - k["iFc"][ri][ti]) <= k["tol_fc"]
+
+
+def test_dvf_dvfShelfCoeffs_known_answers():
+    """test__dvf_dvfShelfCoeffs (test__utilities_module.c:1398-1440): first-order shelf coefficients at 44.1 kHz; calcDVFCoeffs is the
+    same two calls in one."""
+    from oracle import oracle as O
+    k = DVF["shelf_coeffs"]
+    for ri, rho in enumerate(k["rho"]):
+        for ti, th in enumerate(k["theta"]):
+            b0, b1, a1 = O.dvfShelfCoeffs(*O.interpDVFShelfParams(th, rho), k["fs"])
+            assert abs(b0 - k["b0"][ri][ti]) <= k["tol"] and abs(b1 - k["b1"][ri][ti]) <= k["tol"] and abs(a1 - k["a1"][ri][ti]) <= k["tol"]
+            b, a = O.calcDVFCoeffs(th, rho, k["fs"])
+            assert (b[0], b[1], a[1]) == (np.float32(b0), np.float32(b1), np.float32(a1)) and a[0] == 1.0
+
+
+def test_dvf_evalIIRTransferFunctionf_known_answers():
+    """The 12 DVF filters of test__evalIIRTransferFunction (test__utilities_module.c:1114-1190), float-coefficient form, with the
+    reference's own tolerances (0.1 dB + 2/120 per dB of level; 5 degrees of phase)."""
+    from oracle import oracle as O
+    k = DVF["iir"]
+    for t in range(12):
+        mag, ph = O.evalIIRTransferFunctionf(k["b"][t], k["a"][t], k["freqs"], k["fs"])
+        ref_db = 20 * np.log10(np.array(k["mags"][t]))
+        assert np.all(np.abs(20 * np.log10(mag) - ref_db) <= k["tol"]["mag_dB"] + k["tol"]["errScale"] * np.abs(ref_db))
+        assert np.all(np.abs(ph - np.array(k["phases"][t])) <= k["tol"]["phase"])
+        # the restatement is far inside those tolerances (the 2.23e-7 added to the denominator, saf_utility_filters.c:655, costs up
+        # to 7e-5 relative where |A(w)|^2 is 2e-3)
+        assert np.abs(mag / np.array(k["mags"][t]) - 1).max() < 1e-4 and np.abs(ph - np.array(k["phases"][t])).max() < 2e-5
+
+
+def test_dvf_doaToIpsiInteraural_geometry():
+    """doaToIpsiInteraural (saf_utility_dvf.c:192-232; no reference test): the lateral angle of the left ear is the angle between the
+    source and the +y (left) axis, the right ear's is its supplement."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    for az, el in zip(rng.uniform(-180, 180, 50), rng.uniform(-90, 90, 50)):
+        al, _ = O.doaToIpsiInteraural(float(az), float(el))
+        y = np.cos(np.radians(el)) * np.sin(np.radians(az))
+        assert abs(al[0] - np.degrees(np.arccos(np.clip(y, -1, 1)))) < 2e-3 and abs(al[0] + al[1] - 180) < 1e-4

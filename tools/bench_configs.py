@@ -263,6 +263,31 @@ def main():
                 "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": nS * F * 4 + 2 * F * 4, "path_achieved_GBps": round((nS * F * 4 + 2 * F * 4) * nI * nF / t / 1e9, 1), "peak_GBps": HBM},
                 "cpu_baseline": out[1]["cpu_baseline"]})
 
+    # ---- binauraliser_nf: 16 handles x 64 near-field sources in one batch; one source per handle changes distance before every call
+    F, nS, nI, nF = 128, 64, 16, 64
+    def mknf(cls):
+        b = cls(F, 64); b.setHRIRs(h, d, 48000); b.init(48000); b.setNumSources(nS); b.initCodec()
+        rng = np.random.default_rng(19)
+        for s in range(nS):
+            b.setSourceAzi_deg(s, float(rng.uniform(-180, 180))); b.setSourceElev_deg(s, float(rng.uniform(-80, 80))); b.setSourceDist_m(s, float(rng.uniform(0.15, 3.0)))
+        return b
+    nfs = [mknf(api.BinauraliserNF) for _ in range(nI)]
+    bn = api.BinauraliserBatch(nfs, nF)
+    x = torch.rand(nI, nS, nF * F, device="cuda") * 2 - 1; y = torch.zeros(nI, 2, nF * F, device="cuda")
+    tick = [0]
+    def nf_call():
+        tick[0] += 1
+        for b in nfs:
+            b.setSourceDist_m(tick[0] % nS, 0.2 + 0.01 * (tick[0] % 100))
+        bn.process_ptr(x.data_ptr(), (nS * nF * F, F, nF * F), nS, y.data_ptr(), (2 * nF * F, F, nF * F), nF)
+    t, per = timed(L, torch, nf_call, steps, warm, ["afstft_analysis", "dvf_scale", "binaural_mac", "afstft_synthesis"])
+    on = mknf(O.BinauraliserNF); xn = frames(2, nS, F)
+    tc = cpu_time(lambda: on.process(xn), 6.0)
+    out.append({"config": "binauraliser_nf batch: 16 handles x 64 near-field sources, 128-sample blocks, one distance per handle changed before every call", "value": round(nI * nF / t, 1), "unit": "frames/s",
+                "batch": f"{nI} handles x {nF} blocks per call", "kernels_ms": per,
+                "roofline": {"bound": "hbm", "path_alg_bytes_per_frame": nS * F * 4 + 2 * F * 4, "path_achieved_GBps": round((nS * F * 4 + 2 * F * 4) * nI * nF / t / 1e9, 1), "peak_GBps": HBM},
+                "cpu_baseline": {"value": round(1.0 / tc, 1), "unit": "frames/s", "cores": 1, "kind": "port"}})
+
     # ---- SURVEY 8f-4 (second half): ambi_bin order 7 -> 2 ears (MagLS, max-rE), F = 512, one handle
     F, nF = 512, 64
     def mkab(cls):

@@ -2,6 +2,7 @@
 """Per-call latency of the unchanged host-pointer entry points (one block per call: copy in, kernels, copy out, sync) —
 what a real-time host sees.  The channel-pointer tables are built once and the C entry points are called directly, so
 the numbers are those of the C-ABI, not of the Python convenience wrappers.   python tools/latency.py"""
+import ctypes as C
 import json
 import sys
 import time
@@ -54,6 +55,18 @@ def main():
         x = frames(3, 64, 128)
         call, keep = direct(L.binauraliser_process, b.h, x, 2, 128)
         r = lat(call); r["op"] = "binauraliser_process 64 sources, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        bn = api.BinauraliserNF(128, 64); bn.setHRIRs(h, dd, 48000); bn.init(48000); bn.setNumSources(64); bn.initCodec()
+        for s in range(64):
+            bn.setSourceAzi_deg(s, float(5 * s - 160)); bn.setSourceDist_m(s, 0.2 + 0.04 * s)
+        x = frames(3, 64, 128)
+        call, keep = direct(L.binauraliserNF_process, bn.h, x, 2, 128)
+        r = lat(call); r["op"] = "binauraliserNF_process 64 near-field sources, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        k = [0]
+        def moving():
+            k[0] += 1
+            L.binauraliserNF_setSourceDist_m(bn.h, k[0] % 64, C.c_float(0.2 + 0.01 * (k[0] % 50)))
+            call()
+        r = lat(moving); r["op"] = "binauraliserNF_process 64 near-field sources, one distance changed per block, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
         pn = api.Panner(128); pn.setOutputConfigPreset(29); pn.setInputConfigPreset(30); pn.setNumSources(32); pn.initCodec(); pn.init(48000)
         x = frames(4, 32, 128)
         call, keep = direct(L.panner_process, pn.h, x, 64, 128)
