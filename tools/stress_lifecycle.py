@@ -48,6 +48,13 @@ def main():
         b = api.Binauraliser(128, 64); b.setHRIRs(h, d, 48000); b.init(48000); b.setNumSources(8); b.initCodec(); return b
     worst = min(worst, loop("binauraliser", bina, lambda b: [b.process(x64[:8, :128]) for _ in range(3)], n=15))
 
+    def binf():
+        b = api.BinauraliserNF(128, 64); b.setHRIRs(h, d, 48000); b.init(48000); b.setNumSources(8); b.initCodec()
+        for i in range(8):
+            b.setSourceDist_m(i, 0.2 + 0.3 * i)
+        return b
+    worst = min(worst, loop("binauraliser_nf", binf, lambda b: [b.process(x64[:8, :128]) for _ in range(3)], n=15))
+
     def pan():
         p = api.Panner(128); p.setOutputConfigPreset(21); p.setNumSources(4); p.initCodec(); p.init(48000); return p
     worst = min(worst, loop("panner", pan, lambda p: [p.process(x64[:4, :128], 24) for _ in range(3)], n=15))
