@@ -71,7 +71,8 @@ struct Binauraliser {
     DevBuf<float> d_mag, d_itds, d_gtComp, d_freq, d_dirs, d_gains;
     DevBuf<int> d_gtIdx, d_recalc;
     PinBuf<float> stF; PinBuf<int> stI;
-    std::vector<float> shadowGains;
+    std::vector<float> shadowGains, freqOnDevice;
+    bool stagingBusy = false;               /* a kernel or copy enqueued by a device-entry call may still read stF / stI / stDvf */
     PinBuf<float> h_in, h_out;
     DevBuf<float> d_in, d_out;
     /* binauraliser_nf (binauraliser_nf_internal.h:140-158) */
@@ -189,6 +190,15 @@ static void upload_tables(Binauraliser* p)
     p->tablesOnDevice = p->tablesEpoch;
 }
 
+/* band centre frequencies on the device; they change only with the sample rate (binauraliser_init) */
+static void upload_freq(Binauraliser* p)
+{
+    if (p->freqOnDevice.size() == SAF_NBANDS && memcmp(p->freqOnDevice.data(), p->freqVector, sizeof(p->freqVector)) == 0) return;
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    HIP_CHECK(hipMemcpy(p->d_freq.p, p->freqVector, sizeof(p->freqVector), hipMemcpyHostToDevice));
+    p->freqOnDevice.assign(p->freqVector, p->freqVector + SAF_NBANDS);
+}
+
 /* rotate source directions (binauraliser.c:230-248) */
 static void rotate_sources(Binauraliser* p)
 {
@@ -247,8 +257,11 @@ static void process_dev(Binauraliser* p, const float* d_in, long long in_frame, 
     /* interpolate the HRTFs of the sources that moved (binauraliser.c:252-260) */
     bool any = false;
     for (int ch = 0; ch < nS; ch++) any = any || p->recalc_hrtf_interpFLAG[ch];
+    /* zero-copy mode: the small parameter tables are read by the kernels straight from the pinned staging blocks (no copies
+     * on the stream); the host-pointer entry ends every call with a stream sync, so nothing is waited for here either */
+    const bool zc = zero_copy_io();
     if (any) {
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        if (p->stagingBusy) { HIP_CHECK(hipStreamSynchronize(stream())); p->stagingBusy = false; }
         const std::vector<float>& dirs = p->enableRotation ? p->src_dirs_rot_deg : p->src_dirs_deg;
         memcpy(p->stF.p, dirs.data(), sizeof(float) * 2 * nS);
         for (int ch = 0; ch < nS; ch++) {
@@ -256,29 +269,31 @@ static void process_dev(Binauraliser* p, const float* d_in, long long in_frame, 
             if (p->nf && p->recalc_hrtf_interpFLAG[ch]) { p->recalc_dvfCoeffFLAG[ch] = 1; p->curRot = p->enableRotation; p->dvfCoefOnDevice.clear(); }
             p->recalc_hrtf_interpFLAG[ch] = 0;
         }
-        HIP_CHECK(hipMemcpyAsync(p->d_dirs.p, p->stF.p, sizeof(float) * 2 * nS, hipMemcpyHostToDevice, stream()));
-        HIP_CHECK(hipMemcpyAsync(p->d_recalc.p, p->stI.p, sizeof(int) * nS, hipMemcpyHostToDevice, stream()));
-        memcpy(p->stF.p + 2 * p->maxSrc, p->freqVector, sizeof(float) * SAF_NBANDS);
-        HIP_CHECK(hipMemcpyAsync(p->d_freq.p, p->stF.p + 2 * p->maxSrc, sizeof(float) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
+        if (!zc) {
+            HIP_CHECK(hipMemcpyAsync(p->d_dirs.p, p->stF.p, sizeof(float) * 2 * nS, hipMemcpyHostToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(p->d_recalc.p, p->stI.p, sizeof(int) * nS, hipMemcpyHostToDevice, stream()));
+        }
+        upload_freq(p);
         HrtfInterpLaunch l{};
-        l.srcDirs = p->d_dirs.p; l.recalc = p->d_recalc.p; l.gtComp = p->d_gtComp.p; l.gtIdx = p->d_gtIdx.p;
+        l.srcDirs = zc ? p->stF.p : p->d_dirs.p; l.recalc = zc ? p->stI.p : p->d_recalc.p; l.gtComp = p->d_gtComp.p; l.gtIdx = p->d_gtIdx.p;
         l.hrtf_fb = p->d_hrtf_fb.p; l.hrtf_mag = p->d_mag.p; l.itds = p->d_itds.p; l.freq = p->d_freq.p;
         l.hrtf_interp = p->d_hrtf_interp.p; l.nSrc = nS; l.N = p->N_hrir_dirs; l.mode = p->interpMode;
         l.aziRes = p->hrtf_vbapTableRes[0]; l.elevRes = p->hrtf_vbapTableRes[1];
         launch_hrtf_interp(l);
+        p->stagingBusy = true;
     }
     const bool useNF = p->nf && nearField;
     if (useNF && nf_refresh_coeffs(p)) {
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        if (p->stagingBusy && !any) { HIP_CHECK(hipStreamSynchronize(stream())); p->stagingBusy = false; }      /* stDvf is only read by this kernel */
         memcpy(p->stDvf.p, p->dvfCoef.data(), sizeof(float) * (size_t)nS * 8);
-        memcpy(p->stDvf.p + (size_t)p->maxSrc * 8, p->freqVector, sizeof(float) * SAF_NBANDS);
-        HIP_CHECK(hipMemcpyAsync(p->d_dvfCoef.p, p->stDvf.p, sizeof(float) * (size_t)nS * 8, hipMemcpyHostToDevice, stream()));
-        HIP_CHECK(hipMemcpyAsync(p->d_freq.p, p->stDvf.p + (size_t)p->maxSrc * 8, sizeof(float) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
+        if (!zc) HIP_CHECK(hipMemcpyAsync(p->d_dvfCoef.p, p->stDvf.p, sizeof(float) * (size_t)nS * 8, hipMemcpyHostToDevice, stream()));
+        upload_freq(p);
         p->dvfCoefOnDevice = p->dvfCoef;
         DvfScaleLaunch d{};
-        d.hrtf_interp = p->d_hrtf_interp.p; d.coef = p->d_dvfCoef.p; d.freq = p->d_freq.p; d.hrtf_nf = p->d_hrtf_nf.p;
+        d.hrtf_interp = p->d_hrtf_interp.p; d.coef = zc ? p->stDvf.p : p->d_dvfCoef.p; d.freq = p->d_freq.p; d.hrtf_nf = p->d_hrtf_nf.p;
         d.fs = (float)p->fs; d.nSrc = nS;
         launch_dvf_scale(d);
+        p->stagingBusy = true;
     }
     BinMacLaunch m{};
     m.X = p->X.p; m.x_band = a.out_band; m.x_ch = a.out_ch;
@@ -528,6 +543,7 @@ static void process_host(Binauraliser* p, const float* const* inputs, float** co
             HIP_CHECK(hipMemcpyAsync(p->h_out.p, d_o, sizeof(float) * (size_t)2 * F, hipMemcpyDeviceToHost, stream()));
         }
         HIP_CHECK(hipStreamSynchronize(stream()));
+        p->stagingBusy = false;
         int ch;
         for (ch = 0; ch < (2 < nOutputs ? 2 : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);
         for (; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);

@@ -55,6 +55,13 @@ def main():
         x = frames(3, 64, 128)
         call, keep = direct(L.binauraliser_process, b.h, x, 2, 128)
         r = lat(call); r["op"] = "binauraliser_process 64 sources, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        L.binauraliser_setEnableRotation(b.h, 1)
+        yk = [0]
+        def tracked():
+            yk[0] += 1
+            L.binauraliser_setYaw(b.h, C.c_float(float(yk[0] % 90)))
+            call()
+        r = lat(tracked); r["op"] = "binauraliser_process 64 sources, head yaw changed every block (all HRTFs re-interpolated), F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
         bn = api.BinauraliserNF(128, 64); bn.setHRIRs(h, dd, 48000); bn.init(48000); bn.setNumSources(64); bn.initCodec()
         for s in range(64):
             bn.setSourceAzi_deg(s, float(5 * s - 160)); bn.setSourceDist_m(s, 0.2 + 0.04 * s)
