@@ -92,6 +92,8 @@ struct Beamformer {
     PinBuf<int> hi;
     float shadowGain[64];
     int shadowI[3] = { -1, -1, -1 };
+    int cur = 0;                                /* Afrag slot holding W; the other one holds prevW (swapped, not copied) */
+    bool stagingBusy = false;                   /* hA may still be read by a copy enqueued by a device-entry call */
 };
 
 static void bf_setup(Beamformer* p)
@@ -118,6 +120,7 @@ static void bf_run(Beamformer* p, const float* in, long long in_frame, long long
     const int F = p->F, order = p->beamOrder, nSH = ORDER2NSH(order), nBeams = p->nBeams;
     if (p->clearState) {                                     /* beamformer_init (beamformer.c:82-84) */
         HIP_CHECK(hipMemsetAsync(p->prev[p->par].p, 0, sizeof(float) * (size_t)SAF_MAXCH * F, stream()));
+        HIP_CHECK(hipMemsetAsync(p->Afrag.p, 0, sizeof(float) * 2 * 4096, stream()));      /* beamWeights and prev_beamWeights are zeroed with the state */
         p->clearState = false;
     }
     /* input normalisation -> N3D as the per-row input gain (saf_hoa.c:72-116) */
@@ -147,10 +150,12 @@ static void bf_run(Beamformer* p, const float* in, long long in_frame, long long
         mix = 1;
     }
     if (mix) {
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        if (p->stagingBusy) { HIP_CHECK(hipStreamSynchronize(stream())); p->stagingBusy = false; }
         /* rows beyond nBeams stay as they are in the reference's gemm (not computed); here they are not stored (nOut) */
-        pack_A(p->W, p->hA.p); pack_A(p->prevW, p->hA.p + 4096);
-        HIP_CHECK(hipMemcpyAsync(p->Afrag.p, p->hA.p, sizeof(float) * 2 * 4096, hipMemcpyHostToDevice, stream()));
+        p->cur ^= 1;
+        pack_A(p->W, p->hA.p);
+        HIP_CHECK(hipMemcpyAsync(p->Afrag.p + p->cur * 4096, p->hA.p, sizeof(float) * 4096, hipMemcpyHostToDevice, stream()));
+        p->stagingBusy = true;
     }
     const int nSrc = nSH < nIn ? nSH : nIn;
     /* the kernels bound the output rows by (order+1)^2: give them the order that covers the beams */
@@ -165,16 +170,13 @@ static void bf_run(Beamformer* p, const float* in, long long in_frame, long long
     e.in = in; e.in_inst = 0; e.in_frame = in_frame; e.in_ch = in_ch;
     e.out = out; e.out_inst = 0; e.out_frame = out_frame; e.out_ch = out_ch;
     e.prev_rd = p->prev[p->par].p; e.prev_wr = p->prev[p->par ^ 1].p;
-    e.Afrag = p->Afrag.p; e.postScale = p->fpar.p; e.gains = p->fpar.p + 1; e.rowScale = p->fpar.p + 65;
+    e.Afrag = p->Afrag.p + p->cur * 4096; e.AfragPrev = p->Afrag.p + (p->cur ^ 1) * 4096; e.postScale = p->fpar.p; e.gains = p->fpar.p + 1; e.rowScale = p->fpar.p + 65;
     e.nSrc = p->ipar.p; e.mix = mix ? p->ipar.p + 1 : nullptr; e.order = p->ipar.p + 2; e.rowMap = p->ipar.p + 3;
     e.F = F; e.nFrames = nFrames; e.nInst = 1; e.nOut = nOut < nBeams ? nOut : nBeams;
     e.maxSteps = (nSrc + 1) / 2;
     launch_enc_gemm(e);
     p->par ^= 1;
-    if (mix) {                                               /* prev_beamWeights <- beamWeights (beamformer.c:171) */
-        memcpy(p->prevW, p->W, sizeof(p->W));
-        HIP_CHECK(hipMemcpyAsync(p->Afrag.p + 4096, p->Afrag.p, sizeof(float) * 4096, hipMemcpyDeviceToDevice, stream()));
-    }
+    if (mix) memcpy(p->prevW, p->W, sizeof(p->W));            /* prev_beamWeights <- beamWeights (beamformer.c:171): on the device the slots swap at the next change */
 }
 
 }  // namespace saf
@@ -271,6 +273,7 @@ void beamformer_process(void* const hBeam, const float* const* inputs, float** c
         if (nOut) HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nOut * F, hipMemcpyDeviceToHost, stream()));
     }
     HIP_CHECK(hipStreamSynchronize(stream()));
+    p->stagingBusy = false;
     for (int ch = 0; ch < nOut; ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);
     for (int ch = nOut; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);
 }

@@ -210,7 +210,7 @@ __device__ __forceinline__ void enc_frame(const EncLaunch& e, int frame, int ins
     const long long xrow = fromState ? e.F : e.in_ch;
     const bool mix = CANMIX && fromState && e.mix != nullptr && e.mix[inst] != 0;
     const float* A = e.Afrag + ((long long)inst * 2 * 2 + rt) * 32 * 64 + lane;          /* Y */
-    const float* Ap = A + 2 * 32 * 64;                                                    /* prev_Y */
+    const float* Ap = e.AfragPrev ? e.AfragPrev + ((long long)inst * 2 * 2 + rt) * 32 * 64 + lane : A + 2 * 32 * 64;     /* prev_Y */
 
     /* SMALL (few sources): the output row tables are fetched before the product so that their latency hides under it,
      * and since rows >= nSH of Y and columns >= nSrc are zero, a row tile without SH rows and the k-steps past the last
@@ -376,6 +376,12 @@ void launch_enc_gemm(const EncLaunch& e)
     /* only block 0 of a call can cross-fade (direction changes arrive between calls): it alone runs the
      * variant that carries a second accumulator tile */
     const int first = e.mix ? 1 : 0;
+    if (first && e.nFrames == 1) {      /* one-block call with a cross-fade (head tracking): the block and the state copy in one launch */
+        a.frameBase = 0;
+        hipLaunchKernelGGL((enc_gemm_kernel<true, false>), dim3((e.F + 127) / 128, 2, e.nInst), dim3(128), 0, stream(), a);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (first) {
         a.frameBase = 0;
         hipLaunchKernelGGL((enc_gemm_kernel<true, false>), dim3((e.F + 127) / 128, 1, e.nInst), dim3(128), 0, stream(), a);

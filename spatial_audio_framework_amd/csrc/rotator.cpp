@@ -31,7 +31,8 @@ struct Rotator {
     /* device side */
     bool ready = false, clearState = true;
     int maxFrames = 1, par = 0;
-    DevBuf<float> Afrag;                     /* [2 = {M_rot, prev_M_rot}][2][32][64] */
+    DevBuf<float> Afrag;                     /* two slots [2][32][64]: M_rot in slot `cur`, prev_M_rot in the other (swapped, not copied) */
+    int cur = 0;
     DevBuf<float> prev[2];                   /* [64][F] previous block (ping-pong) */
     DevBuf<float> fpar;                      /* postScale | gains[64] | rowScale[64] */
     DevBuf<int> ipar;                        /* nSrc | mix | order | rowMap[64] */
@@ -39,6 +40,7 @@ struct Rotator {
     PinBuf<int> hi;
     DevBuf<float> d_in, d_out;
     int shadowI[3] = { -1, -1, -1 };
+    bool stagingBusy = false;                /* hA may still be read by a copy enqueued by a device-entry call */
 };
 
 static void rot_setup(Rotator* p)
@@ -64,6 +66,7 @@ static void rot_run(Rotator* p, const float* in, long long in_frame, long long i
     const int F = p->F, order = p->inputOrder, nSH = ORDER2NSH(order);
     if (p->clearState) {                                     /* rotator_init (rotator.c:93-96) */
         HIP_CHECK(hipMemsetAsync(p->prev[p->par].p, 0, sizeof(float) * (size_t)SAF_MAXCH * F, stream()));
+        HIP_CHECK(hipMemsetAsync(p->Afrag.p, 0, sizeof(float) * 2 * 4096, stream()));      /* M_rot and prev_M_rot are zeroed with the state (rotator.c:93-96) */
         p->clearState = false;
     }
     int mix = 0;
@@ -82,9 +85,11 @@ static void rot_run(Rotator* p, const float* in, long long in_frame, long long i
         for (int i = 0; i < nSH; i++) for (int j = 0; j < nSH; j++) p->M_rot[i * 64 + j] = M[(size_t)i * nSH + j];
         mix = 1;
         p->M_rot_status = M_ROT_READY;
-        HIP_CHECK(hipStreamSynchronize(stream()));           /* the staging buffer may still be in flight */
-        pack_A(p->M_rot, p->hA.p); pack_A(p->prev_M_rot, p->hA.p + 4096);
-        HIP_CHECK(hipMemcpyAsync(p->Afrag.p, p->hA.p, sizeof(float) * 2 * 4096, hipMemcpyHostToDevice, stream()));
+        if (p->stagingBusy) { HIP_CHECK(hipStreamSynchronize(stream())); p->stagingBusy = false; }     /* the staging buffer may still be in flight */
+        p->cur ^= 1;                                         /* the slot of the matrix before last is free; the other one holds prev_M_rot */
+        pack_A(p->M_rot, p->hA.p);
+        HIP_CHECK(hipMemcpyAsync(p->Afrag.p + p->cur * 4096, p->hA.p, sizeof(float) * 4096, hipMemcpyHostToDevice, stream()));
+        p->stagingBusy = true;
     }
     const int nSrc = nSH < nIn ? nSH : nIn;
     if (p->shadowI[0] != nSrc || p->shadowI[1] != mix || p->shadowI[2] != order) {
@@ -98,16 +103,13 @@ static void rot_run(Rotator* p, const float* in, long long in_frame, long long i
     e.in = in; e.in_inst = 0; e.in_frame = in_frame; e.in_ch = in_ch;
     e.out = out; e.out_inst = 0; e.out_frame = out_frame; e.out_ch = out_ch;
     e.prev_rd = p->prev[p->par].p; e.prev_wr = p->prev[p->par ^ 1].p;
-    e.Afrag = p->Afrag.p; e.postScale = p->fpar.p; e.gains = p->fpar.p + 1; e.rowScale = p->fpar.p + 65;
+    e.Afrag = p->Afrag.p + p->cur * 4096; e.AfragPrev = p->Afrag.p + (p->cur ^ 1) * 4096; e.postScale = p->fpar.p; e.gains = p->fpar.p + 1; e.rowScale = p->fpar.p + 65;
     e.nSrc = p->ipar.p; e.mix = mix ? p->ipar.p + 1 : nullptr; e.order = p->ipar.p + 2; e.rowMap = p->ipar.p + 3;
     e.F = F; e.nFrames = nFrames; e.nInst = 1; e.nOut = nOut < SAF_MAXCH ? nOut : SAF_MAXCH;
     e.maxSteps = (nSrc + 1) / 2;
     launch_enc_gemm(e);
     p->par ^= 1;
-    if (mix) {                                               /* prev_M_rot <- M_rot (rotator.c:170) */
-        memcpy(p->prev_M_rot, p->M_rot, sizeof(p->M_rot));
-        HIP_CHECK(hipMemcpyAsync(p->Afrag.p + 4096, p->Afrag.p, sizeof(float) * 4096, hipMemcpyDeviceToDevice, stream()));
-    }
+    if (mix) memcpy(p->prev_M_rot, p->M_rot, sizeof(p->M_rot));     /* prev_M_rot <- M_rot (rotator.c:170): on the device the slots swap at the next change */
 }
 
 }  // namespace saf
@@ -241,6 +243,7 @@ void rotator_process(void* const hRot, const float* const* inputs, float** const
         HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nSH * F, hipMemcpyDeviceToHost, stream()));
     }
     HIP_CHECK(hipStreamSynchronize(stream()));
+    p->stagingBusy = false;
     for (int c = 0; c < nSH; c++) {
         const int dst = fuma ? fuma2acn[c] : c;                           /* ACN channel c goes to FuMa channel fuma2acn[c] */
         if (dst < nOutputs) memcpy(outputs[dst], p->h_out.p + (size_t)c * F, sizeof(float) * F);

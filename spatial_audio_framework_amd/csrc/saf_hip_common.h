@@ -194,6 +194,8 @@ struct EncLaunch {
     float* out;      long long out_inst, out_frame, out_ch;
     const float* prev_rd; float* prev_wr;     /* [nInst][64][F] */
     const float* Afrag;                       /* [nInst][2 = {Y, prev_Y}][2][32][64] */
+    const float* AfragPrev = nullptr;         /* when set: prev_Y of instance i is AfragPrev + i*2*4096 instead of the second half of its Afrag
+                                               * entry (operators that keep two matrix slots and swap them instead of copying) */
     const float* gains;                       /* [nInst][64] effective per-source gain */
     const float* postScale;                   /* [nInst] 1/sqrt(nSources) or 1 */
     const float* rowScale;                    /* [nInst][64] N3D -> output norm, by ACN row */

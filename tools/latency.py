@@ -78,10 +78,41 @@ def main():
         x = frames(4, 32, 128)
         call, keep = direct(L.panner_process, pn.h, x, 64, 128)
         r = lat(call); r["op"] = "panner_process 32 sources -> 64 loudspeakers, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        pk = [0]
+        def pan_moving():
+            pk[0] += 1
+            L.panner_setSourceAzi_deg(pn.h, pk[0] % 32, C.c_float(float(pk[0] % 170)))
+            call()
+        r = lat(pan_moving); r["op"] = "panner_process 32 sources -> 64 loudspeakers, one source moved per block, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        ek = [0]
+        xe = frames(2, 4, 256)
+        ecall, ekeep = direct(L.ambi_enc_process, e.h, xe, 4, 256)
+        def enc_moving():
+            ek[0] += 1
+            L.ambi_enc_setSourceAzi_deg(e.h, ek[0] % 4, C.c_float(float(ek[0] % 170)))
+            ecall()
+        r = lat(enc_moving); r["op"] = "ambi_enc_process 4 sources, order 1, one source moved per block, F = 256" + tag; r["block_us"] = round(256 / 48000 * 1e6, 1); out.append(r)
+        ab = api.AmbiBin(128); ab.setHRIRs(h, dd, 48000); ab.setInputOrderPreset(3); ab.init(48000); ab.initCodec()
+        xa = frames(8, 16, 128)
+        acall, akeep = direct(L.ambi_bin_process, ab.h, xa, 2, 128)
+        r = lat(acall); r["op"] = "ambi_bin_process order 3, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        L.ambi_bin_setEnableRotation(ab.h, 1)
+        ak = [0]
+        def bin_tracked():
+            ak[0] += 1
+            L.ambi_bin_setYaw(ab.h, C.c_float(float(ak[0] % 90)))
+            acall()
+        r = lat(bin_tracked); r["op"] = "ambi_bin_process order 3, head yaw changed every block, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
         ro = api.Rotator(128); ro.init(48000); ro.setOrder(7); ro.setYaw(30.0)
         x = frames(6, 64, 128)
         call, keep = direct(L.rotator_process, ro.h, x, 64, 128)
         r = lat(call); r["op"] = "rotator_process order 7, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        rk = [0]
+        def rot_tracked():
+            rk[0] += 1
+            L.rotator_setYaw(ro.h, C.c_float(float(rk[0] % 90)))
+            call()
+        r = lat(rot_tracked); r["op"] = "rotator_process order 7, yaw changed every block, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
         H = (np.random.default_rng(3).normal(size=(2, 256, 1024)) / 32).astype(np.float32)
         mc = api.MatrixConv(512, H, 1)
         xi = np.ascontiguousarray(frames(5, 256, 512)); yo = np.zeros((2, 512), np.float32)
