@@ -32,7 +32,7 @@ struct AmbiBin {
     std::vector<float> hrirs, hrir_dirs_deg, itds_s, weights;
     std::vector<float2> hrtf_fb;
     int N_hrir_dirs = 0, hrir_len = 0, hrir_fs = 0;
-    std::vector<std::complex<float>> M_dec, M_dec_rot;      /* [133][2][64] */
+    std::vector<std::complex<float>> M_dec;                 /* [133][2][64]; M_dec_rot lives on the device only (d_decRot) */
     volatile CODEC_STATUS codecStatus;
     volatile PROC_STATUS procStatus;
     float progressBar0_1 = 0.0f; char progressBarText[PROGRESSBARTEXT_CHAR_LENGTH];
@@ -46,10 +46,12 @@ struct AmbiBin {
     /* device side */
     AfState st;
     int Hmax = 0;
-    DevBuf<float2> X, Y, d_dec;
+    DevBuf<float2> X, Y, d_dec /* M_dec, MAC layout */, d_decRot /* M_dec_rot, MAC layout */, d_MdecBase /* [133][2][64] */;
+    DevBuf<float> d_Mrot; PinBuf<float> stR;
+    bool stagingBusy = false;               /* stD / stR may still be read by a copy enqueued by a device-entry call */
     DevBuf<float> d_scale, d_in, d_out; DevBuf<int> d_map;
     PinBuf<float> stS, h_in, h_out; PinBuf<int> stM; PinBuf<float2> stD;
-    bool decDirty = true; int decRotOnDevice = -1;
+    bool decDirty = true;
     int shNorm = -1, shOrd = -1, shOrder = -1;
 };
 
@@ -93,34 +95,29 @@ static void process_dev(AmbiBin* p, const float* d_in, long long in_frame, long 
 
     /* rotation baked into the decoder when flagged (ambi_bin.c:437-456) */
     const int useRot = order > 0 && p->enableRotation ? 1 : 0;
+    if (p->decDirty) {                                       /* a new decoder: its rows to the device, M_dec in the MAC's layout */
+        if (p->stagingBusy) { HIP_CHECK(hipStreamSynchronize(stream())); p->stagingBusy = false; }
+        for (size_t i = 0; i < p->M_dec.size(); i++) p->stD.p[i] = make_float2(p->M_dec[i].real(), p->M_dec[i].imag());
+        HIP_CHECK(hipMemcpyAsync(p->d_MdecBase.p, p->stD.p, sizeof(float2) * p->M_dec.size(), hipMemcpyHostToDevice, stream()));
+        DecRotLaunch r{}; r.Mdec = p->d_MdecBase.p; r.Mrot = nullptr; r.out = p->d_dec.p; r.nSH = nSH;
+        launch_dec_rotate(r);
+        p->decDirty = false; p->stagingBusy = true;
+    }
     if (useRot && p->recalc_M_rotFLAG) {
         float R[3][3];
         yaw_pitch_roll_to_Rzyx(p->yaw, p->pitch, p->roll, p->useRollPitchYawFlag, R);
-        std::vector<float> Mrot((size_t)nSH * nSH);
-        sh_rot_matrix_real(R, Mrot.data(), order);
-        for (int b = 0; b < SAF_NBANDS; b++) for (int e = 0; e < 2; e++) for (int j = 0; j < nSH; j++) {
-            std::complex<float> s = 0.0f;
-            for (int k = 0; k < nSH; k++) s += p->M_dec[((size_t)b * 2 + e) * SAF_MAXCH + k] * Mrot[(size_t)k * nSH + j];
-            p->M_dec_rot[((size_t)b * 2 + e) * SAF_MAXCH + j] = s;
-        }
-        p->recalc_M_rotFLAG = 0; p->decDirty = true;
+        if (p->stagingBusy) { HIP_CHECK(hipStreamSynchronize(stream())); p->stagingBusy = false; }
+        sh_rot_matrix_real(R, p->stR.p, order);
+        HIP_CHECK(hipMemcpyAsync(p->d_Mrot.p, p->stR.p, sizeof(float) * (size_t)nSH * nSH, hipMemcpyHostToDevice, stream()));
+        DecRotLaunch r{}; r.Mdec = p->d_MdecBase.p; r.Mrot = p->d_Mrot.p; r.out = p->d_decRot.p; r.nSH = nSH;
+        launch_dec_rotate(r);
+        p->recalc_M_rotFLAG = 0; p->stagingBusy = true;
     }
     /* (with rotation enabled the reference multiplies by M_dec_rot whatever its age, ambi_bin.c:459-464) */
     const int wantRot = p->enableRotation ? 1 : 0;
-    if (p->decDirty || p->decRotOnDevice != wantRot) {
-        HIP_CHECK(hipStreamSynchronize(stream()));
-        const std::vector<std::complex<float>>& M = wantRot ? p->M_dec_rot : p->M_dec;
-        for (int k = 0; k < SAF_MAXCH; k++) for (int b = 0; b < SAF_NBANDS; b++) for (int e = 0; e < 2; e++) {
-            const std::complex<float> v = k < nSH ? M[((size_t)b * 2 + e) * SAF_MAXCH + k] : std::complex<float>(0.0f, 0.0f);
-            p->stD.p[((size_t)k * SAF_NBANDS + b) * 2 + e] = make_float2(v.real(), v.imag());          /* binaural_mac layout [src][band][ear] */
-        }
-        HIP_CHECK(hipMemcpyAsync(p->d_dec.p, p->stD.p, sizeof(float2) * (size_t)SAF_MAXCH * SAF_NBANDS * 2, hipMemcpyHostToDevice, stream()));
-        HIP_CHECK(hipStreamSynchronize(stream()));
-        p->decDirty = false; p->decRotOnDevice = wantRot;
-    }
     BinMacLaunch m{};
     m.X = p->X.p; m.x_band = a.out_band; m.x_ch = a.out_ch;
-    m.h = p->d_dec.p;
+    m.h = wantRot ? p->d_decRot.p : p->d_dec.p;
     m.Y = p->Y.p; m.y_band = (long long)2 * p->Hmax; m.y_ch = p->Hmax;
     m.nSrc = nSH; m.H = H; m.scale = 1.0f;
     launch_binaural_mac(m);
@@ -151,7 +148,7 @@ void ambi_bin_create(void** const phAmbi)        /* ambi_bin.c:48-109 */
     AmbiBin* p = new AmbiBin();
     *phAmbi = p;
     p->F = g_abin_frame_size; p->T = p->F / SAF_HOP;
-    p->M_dec.assign((size_t)SAF_NBANDS * 2 * SAF_MAXCH, 0.0f); p->M_dec_rot.assign((size_t)SAF_NBANDS * 2 * SAF_MAXCH, 0.0f);
+    p->M_dec.assign((size_t)SAF_NBANDS * 2 * SAF_MAXCH, 0.0f);
     p->codecStatus = CODEC_STATUS_NOT_INITIALISED; p->procStatus = PROC_STATUS_NOT_ONGOING;
     p->progressBarText[0] = 0;
     memset(p->freqVector, 0, sizeof(p->freqVector));
@@ -193,7 +190,8 @@ void ambi_bin_initCodec(void* const hAmbi)                  /* ambi_bin.c:167-37
     HIP_CHECK(hipStreamSynchronize(stream()));
     if (!p->haveSTFT) {
         p->st.create(1, nSH, 2);
-        p->d_dec.alloc((size_t)SAF_MAXCH * SAF_NBANDS * 2); p->d_scale.alloc(SAF_MAXCH); p->d_map.alloc(SAF_MAXCH);
+        p->d_dec.alloc((size_t)SAF_MAXCH * SAF_NBANDS * 2); p->d_decRot.alloc((size_t)SAF_MAXCH * SAF_NBANDS * 2); p->d_MdecBase.alloc((size_t)SAF_NBANDS * 2 * SAF_MAXCH);
+        p->d_Mrot.alloc(64 * 64); p->stR.ensure(64 * 64); p->d_scale.alloc(SAF_MAXCH); p->d_map.alloc(SAF_MAXCH);
         p->stS.ensure(SAF_MAXCH); p->stM.ensure(SAF_MAXCH); p->stD.ensure((size_t)SAF_MAXCH * SAF_NBANDS * 2);
         p->haveSTFT = true;
     } else if (p->nSH != nSH) { p->st.channelChange(nSH, 2); p->st.clear(); }
@@ -279,6 +277,7 @@ void ambi_bin_process(void* const hAmbi, const float* const* inputs, float** con
             HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)2 * F, hipMemcpyDeviceToHost, stream()));
         }
         HIP_CHECK(hipStreamSynchronize(stream()));
+        p->stagingBusy = false;
         int ch;
         for (ch = 0; ch < (2 < nOutputs ? 2 : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);
         for (; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);

@@ -8,6 +8,8 @@
  *   dvf_scale_kernel     binauraliser_nf (binauraliser_nf.c:299-338): response of each near source's two first-order DVF
  *                        shelves at the 133 band centres, multiplied onto the interpolated HRTF (the reference's product
  *                        (magnitude + i phase) * hrtf, kept as it is); far sources pass through.
+ *   dec_rotate_kernel    ambi_bin (ambi_bin.c:437-456): the scene rotation folded into the binaural decoder, per band a
+ *                        [2 x nSH] complex by [nSH x nSH] real product written in the band MAC's operand layout.
  *   binaural_mac_kernel  the band MAC of binauraliser_process (binauraliser.c:252-268): per band a [2 x nSrc] x
  *                        [nSrc x T] complex product.  Spectra rows [src][hop] are read exactly once; the source sum is
  *                        split over the thread groups of a workgroup and folded through LDS.
@@ -104,6 +106,40 @@ void launch_dvf_scale(const DvfScaleLaunch& l)
     DvfArgs a; a.l = l;
     KernelTimer kt("dvf_scale");
     hipLaunchKernelGGL(dvf_scale_kernel, dim3(l.nSrc, l.nInst > 0 ? l.nInst : 1), dim3(192), 0, stream(), a);
+    HIP_CHECK(hipGetLastError());
+}
+
+struct DecRotArgs { DecRotLaunch l; };
+
+/* grid 133 (band), 128 threads = 2 ears x 64 output columns; M_rot and the band's two decoder rows in LDS */
+__global__ __launch_bounds__(128) void dec_rotate_kernel(DecRotArgs a)
+{
+    __shared__ float s_R[64 * 64];
+    __shared__ float2 s_M[2][64];
+    const DecRotLaunch& l = a.l;
+    const int band = blockIdx.x, tid = threadIdx.x, e = tid >> 6, j = tid & 63, nSH = l.nSH;
+    s_M[e][j] = l.Mdec[((long long)band * 2 + e) * 64 + j];
+    if (l.Mrot) for (int i = tid; i < nSH * nSH; i += 128) s_R[i] = l.Mrot[i];
+    __syncthreads();
+    float2 acc = make_float2(0.0f, 0.0f);
+    if (j < nSH) {
+        if (l.Mrot) {
+            for (int k = 0; k < nSH; k++) {
+                const float r = s_R[k * nSH + j];
+                const float2 m = s_M[e][k];
+                acc.x = fmaf(m.x, r, acc.x); acc.y = fmaf(m.y, r, acc.y);
+            }
+        } else acc = s_M[e][j];
+    }
+    l.out[((long long)j * SAF_NBANDS + band) * 2 + e] = acc;
+}
+
+void launch_dec_rotate(const DecRotLaunch& l)
+{
+    if (l.nSH < 1 || l.nSH > 64) SAF_FATAL("dec_rotate: nSH out of range");
+    DecRotArgs a; a.l = l;
+    KernelTimer kt("dec_rotate");
+    hipLaunchKernelGGL(dec_rotate_kernel, dim3(SAF_NBANDS), dim3(128), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 

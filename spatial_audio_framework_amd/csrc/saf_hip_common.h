@@ -262,6 +262,14 @@ struct BinMacLaunch {           /* out[band][ear][t] = scale * sum_src h[src][ba
     int nInst = 1; long long x_inst = 0, y_inst = 0, h_inst = 0;    /* batches: per-instance strides in float2 elements */
 };
 void launch_binaural_mac(const BinMacLaunch& l);
+struct DecRotLaunch {           /* ambi_bin.c:437-456: M_dec_rot[band] = M_dec[band] (2 x nSH, complex) * M_rot (nSH x nSH, real), written in the
+                                 * band MAC's operand layout; Mrot == nullptr copies M_dec into that layout */
+    const float2* Mdec;         /* [133][2][64] */
+    const float* Mrot;          /* [nSH][nSH] row-major, or nullptr */
+    float2* out;                /* [64][133][2]; rows >= nSH are written as zero */
+    int nSH;
+};
+void launch_dec_rotate(const DecRotLaunch& l);
 struct BinFoldLaunch {          /* HM[inst][sh][band][ear] = sum_ls h[inst][ls][band][ear] * A[inst][band2mat[band]][ls][sh]: decoder and HRTFs as ONE 2 x nSH matrix per band */
     const float2* h;            /* [nInst][64][133][2] */
     const float* A;             /* [nInst][nMat][64][64] row-major [ls][sh] */

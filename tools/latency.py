@@ -92,17 +92,18 @@ def main():
             L.ambi_enc_setSourceAzi_deg(e.h, ek[0] % 4, C.c_float(float(ek[0] % 170)))
             ecall()
         r = lat(enc_moving); r["op"] = "ambi_enc_process 4 sources, order 1, one source moved per block, F = 256" + tag; r["block_us"] = round(256 / 48000 * 1e6, 1); out.append(r)
-        ab = api.AmbiBin(128); ab.setHRIRs(h, dd, 48000); ab.setInputOrderPreset(3); ab.init(48000); ab.initCodec()
-        xa = frames(8, 16, 128)
-        acall, akeep = direct(L.ambi_bin_process, ab.h, xa, 2, 128)
-        r = lat(acall); r["op"] = "ambi_bin_process order 3, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
-        L.ambi_bin_setEnableRotation(ab.h, 1)
-        ak = [0]
-        def bin_tracked():
-            ak[0] += 1
-            L.ambi_bin_setYaw(ab.h, C.c_float(float(ak[0] % 90)))
-            acall()
-        r = lat(bin_tracked); r["op"] = "ambi_bin_process order 3, head yaw changed every block, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+        for bo in (3, 7):
+            ab = api.AmbiBin(128); ab.setHRIRs(h, dd, 48000); ab.setInputOrderPreset(bo); ab.init(48000); ab.initCodec()
+            xa = frames(8, (bo + 1) ** 2, 128)
+            acall, akeep = direct(L.ambi_bin_process, ab.h, xa, 2, 128)
+            r = lat(acall); r["op"] = f"ambi_bin_process order {bo}, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
+            L.ambi_bin_setEnableRotation(ab.h, 1)
+            ak = [0]
+            def bin_tracked():
+                ak[0] += 1
+                L.ambi_bin_setYaw(ab.h, C.c_float(float(ak[0] % 90)))
+                acall()
+            r = lat(bin_tracked); r["op"] = f"ambi_bin_process order {bo}, head yaw changed every block, F = 128" + tag; r["block_us"] = round(128 / 48000 * 1e6, 1); out.append(r)
         ro = api.Rotator(128); ro.init(48000); ro.setOrder(7); ro.setYaw(30.0)
         x = frames(6, 64, 128)
         call, keep = direct(L.rotator_process, ro.h, x, 64, 128)
