@@ -167,13 +167,22 @@ typedef enum { AMPLITUDE_PRESERVING = 1, ENERGY_PRESERVING } AMBI_DEC_DIFFUSE_FI
 
 /** The reference fixes the block size at compile time (-DAMBI_DEC_FRAME_SIZE, ambi_dec_internal.h:61-67, default 128).
  *  Here it is a process-wide setting read by ambi_dec_create; must be a multiple of 128. */
-/** Band-independent decoding.  When every band of every instance of a pipeline selects the same (decoder, order) matrix
- *  — the reference's own default configuration does once both decoders use the same method — decoding commutes with the
- *  filterbank: the library then multiplies in the time domain and runs afSTFT analysis -> synthesis of the loudspeaker
- *  signals in its transform-free form (the FFT and inverse FFT cancel, the hybrid split/merge reduces to its 3-hop delay).
- *  Same outputs to rounding (1e-6), same state, selected per call; 0 forces the three-kernel transform path. Default 1. */
-SAF_API void saf_hip_ambi_dec_setTimeDomainPath(int enable);
+/** Block path of loudspeaker decoding.  Every per-band matrix ambi_dec_process applies (ambi_dec.c:518-540) is the
+ *  dense order-N decoder of its band's decoder slot (ambi_dec.c:283-288 only truncates columns) times a diagonal of
+ *  per-SH-channel weights (max-rE, M_norm, order truncation).  The diagonal commutes into the filterbank of each input
+ *  channel and the dense matrix out of it:  out = sum_d M_d synthesis( w_d(band)[ch] (.) analysis(x[ch]) ).
+ *    mode 1 (default): "equaliser path" — one kernel runs analysis -> per-band gains -> synthesis per SH channel with the
+ *            spectra kept on chip, then ONE time-domain MFMA GEMM applies the dense decoder(s); channels whose weights are
+ *            the same in every band skip the transforms (FFT / inverse FFT cancel, the hybrid split + merge is its delay);
+ *    mode 2: as 1, every channel runs the transforms;
+ *    mode 0: the three-kernel transform path (afSTFT analysis -> per-band MFMA GEMM -> afSTFT synthesis).
+ *  Same outputs to rounding (1e-6).  The overlap-add history lives in the SH domain on the equaliser path and in the
+ *  loudspeaker domain on the transform path: switching 1/2 -> 0 converts it (exact); a pipeline that has run mode 0 stays
+ *  on the transform path until its state is cleared (initCodec / saf_hip_ambi_dec_batch_clear).  Binauralised output
+ *  always takes the transform path.  saf_hip_ambi_dec(_batch)_lastPath: 0 transform, 1 equaliser, -1 nothing run yet. */
+SAF_API void saf_hip_ambi_dec_setTimeDomainPath(int mode);
 SAF_API int  saf_hip_ambi_dec_getTimeDomainPath(void);
+SAF_API int  saf_hip_ambi_dec_lastPath(void* const hAmbi);
 SAF_API void saf_hip_ambi_dec_setFrameSize(int frameSize);
 
 SAF_API void ambi_dec_create(void** const phAmbi);                               /* ambi_dec.h:114 */
@@ -243,6 +252,7 @@ SAF_API float saf_hip_ambi_dec_getDecoderNorm(void* const hAmbi, int decIdx, int
 SAF_API void* saf_hip_ambi_dec_batch_create(void* const* hAmbis, int nInst, int maxFramesPerCall);
 SAF_API void  saf_hip_ambi_dec_batch_destroy(void** const phBatch);
 SAF_API void  saf_hip_ambi_dec_batch_clear(void* const hBatch);
+SAF_API int   saf_hip_ambi_dec_batch_lastPath(void* const hBatch);
 SAF_API void  saf_hip_ambi_dec_batch_process(void* const hBatch,
                                              const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride,
                                              float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride,

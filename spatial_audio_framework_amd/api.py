@@ -272,6 +272,10 @@ class AmbiDec:
     def Mnorm(self, dec, order, which):
         return self.L.saf_hip_ambi_dec_getDecoderNorm(self.h, dec, order, which)
 
+    def lastPath(self):
+        """0: transform path, 1: equaliser path, -1: no block processed yet (saf_hip_ambi_dec_setTimeDomainPath)"""
+        return self.L.saf_hip_ambi_dec_lastPath(self.h)
+
     def __del__(self):
         if getattr(self, "h", None) and C is not None:
             self.L.ambi_dec_destroy(C.byref(self.h))
@@ -293,6 +297,9 @@ class AmbiDecBatch:
 
     def clear(self):
         self.L.saf_hip_ambi_dec_batch_clear(self.hb)
+
+    def lastPath(self):
+        return self.L.saf_hip_ambi_dec_batch_lastPath(self.hb)
 
     def __del__(self):
         if getattr(self, "hb", None) and C is not None:

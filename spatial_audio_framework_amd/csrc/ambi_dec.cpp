@@ -28,8 +28,12 @@ namespace saf {
 #define NMAT (NUM_DECODERS * SAF_MAX_ORDER)
 static int g_ambi_dec_frame_size = 128;    /* default of the reference (ambi_dec_internal.h:65) */
 
-/* band-independent decoding takes the time-domain form (DecPipeline::process) unless switched off */
-static int g_ambi_dec_time_domain = []() { const char* e = getenv("SAF_HIP_AMBI_DEC_TIME_DOMAIN"); return e ? atoi(e) != 0 : 1; }();      /* env: 0 = always the transform path */
+/* Which block path loudspeaker decoding takes (DecPipeline::process):
+ *   0  the three-kernel transform path: afSTFT analysis -> per-band MFMA GEMM -> afSTFT synthesis (spectra through HBM)
+ *   1  (default) the equaliser path: per-channel filterbank equaliser (eq_kernels.hip) + ONE time-domain GEMM with the dense
+ *      decoder(s); channels whose weights are the same in every band skip the transforms
+ *   2  as 1, but every channel runs the transforms (what holds for ANY per-band order / decoder / weighting assignment) */
+static int g_ambi_dec_time_domain = []() { const char* e = getenv("SAF_HIP_AMBI_DEC_TIME_DOMAIN"); return e ? atoi(e) : 1; }();
 
 static inline void sleep_ms(int ms) { std::this_thread::sleep_for(std::chrono::milliseconds(ms)); }
 
@@ -78,15 +82,23 @@ struct DecPipeline {
     DevBuf<int> band2mat;           /* [nInst][133] */
     DevBuf<float> chScale;          /* [nInst][64] */
     DevBuf<int> chMap;              /* [nInst][64] */
-    /* band-independent decoding: when every band of every instance uses the same matrix, decoding commutes with the
-     * filterbank: y = A x in the time domain, then analysis -> synthesis of y without the transforms (launch_roundtrip) */
-    DevBuf<float> AfragT;           /* [nInst][2][32][64] the single matrix with the input conventions folded into its columns */
-    DevBuf<float> ybuf;             /* [nInst][64][(15 + Hmax) * 128] */
-    DevBuf<int> b2mT, zerosI;       /* [nInst] matrix index for the history GEMM; zeros [nInst][maxFrames] */
-    std::vector<int> tdMat;         /* per instance: index of the single matrix, -1 when bands differ */
-    std::vector<char> tdDirty;
-    PinBuf<float> stageT; PinBuf<int> stageTi;
-    bool tdTableDirty = true;
+    /* equaliser path (see eq_kernels.hip): every per-band matrix of ambi_dec is M_d diag(w_{d,n}); the diagonal goes into a
+     * per-channel filterbank equaliser, the dense M_d into one time-domain GEMM:  out = sum_d M_d z_d */
+    DevBuf<float> eqGains;          /* [nInst][eqD][64][136] w_{d(band), n(band)}[ch] */
+    DevBuf<int> eqUni;              /* [nInst][64] 1: the channel's gains are the same in every band */
+    DevBuf<float> Mfrag;            /* [nInst][2][2][32][64] the dense decoders M_0, M_1 in MFMA fragment order */
+    DevBuf<float> zbuf;             /* [eqD][nInst][64][Hmax * 128] */
+    DevBuf<float> zsyn[2];          /* ping-pong: [2][nInst][nSH][9][256] synthesised-frame history of z_d (SH domain) */
+    DevBuf<int> zerosI;             /* [nInst][maxFrames] "band -> matrix 0" table of the time-domain GEMM */
+    int zsynPar = 0, eqD = 1;
+    std::vector<char> eqDirty, eqTwo;        /* per instance: tables stale; the two decoders are different matrices */
+    PinBuf<float> stageG, stageM; PinBuf<int> stageU;
+    bool mode2Shadow = false;
+    /* The overlap-add history lives in the loudspeaker domain on the transform path (AfState::syn) and in the SH domain on
+     * the equaliser path (zsyn).  SH -> loudspeaker is exact (st.syn = sum_d M_d zsyn_d, one small GEMM); the other
+     * direction does not exist, so a pipeline that has run the transform path stays on it until its state is cleared. */
+    enum { DOM_NONE, DOM_LS, DOM_SH } synDomain = DOM_NONE;
+    int lastPath = -1;              /* 0 transform, 1 equaliser (saf_hip_ambi_dec_batch_lastPath) */
     /* binauralised output (ambi_dec.c:543-563) */
     bool bin = false;
     std::shared_ptr<HrtfTables> hrtf;
@@ -136,21 +148,118 @@ struct DecPipeline {
             stageD.ensure((size_t)nInst * SAF_MAXCH * 2 + SAF_NBANDS); stageR.ensure((size_t)nInst * SAF_MAXCH);
             for (int i = 0; i < n; i++) for (int ch = 0; ch < SAF_MAXCH; ch++) inst[i]->recalc_hrtf_interpFLAG[ch] = 1;     /* a new pipeline starts without interpolated HRTFs */
         }
-        /* zeroed once: the analysis only ever writes the first nSH channel rows, the GEMM reads all 64
-         * (against zero matrix columns) — stale NaNs there would poison the product */
-        X.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);
-        if (!bin) Y.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);      /* binauralised output never forms the loudspeaker spectra */
+        if (bin) ensure_transform_buffers();
         Afrag.alloc((size_t)nInst * NMAT * 64 * 64);
         band2mat.alloc((size_t)nInst * SAF_NBANDS);
         chScale.alloc((size_t)nInst * SAF_MAXCH);
         chMap.alloc((size_t)nInst * SAF_MAXCH);
         shadow.assign(nInst, Shadow());
-        tdMat.assign(nInst, -1); tdDirty.assign(nInst, 1);
-        if (!bin) {
-            AfragT.alloc((size_t)nInst * 64 * 64); ybuf.alloc((size_t)nInst * SAF_MAXCH * (SAF_ANA_HIST + Hmax) * SAF_HOP, false);
-            b2mT.alloc(nInst); zerosI.alloc((size_t)nInst * maxFrames); stageT.ensure(64 * 64); stageTi.ensure(nInst);
-        }
+        eqDirty.assign(nInst, 1); eqTwo.assign(nInst, 0);
         stageA.ensure((size_t)NMAT * 64 * 64); stageI.ensure(SAF_NBANDS + SAF_MAXCH); stageS.ensure(SAF_MAXCH);
+    }
+
+    /* spectra of the transform path (4.5 GB each at 256 instances x 64 blocks): allocated when that path first runs */
+    void ensure_transform_buffers()
+    {
+        /* zeroed once: the analysis only ever writes the first nSH channel rows, the GEMM reads all 64
+         * (against zero matrix columns) — stale NaNs there would poison the product */
+        if (!X.p) X.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);
+        if (!bin && !Y.p) Y.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);      /* binauralised output never forms the loudspeaker spectra */
+    }
+    void ensure_eq_buffers(int D)
+    {
+        if (!eqGains.p || D > eqD) {
+            HIP_CHECK(hipStreamSynchronize(stream()));
+            const int oldD = eqGains.p ? eqD : 0;
+            eqD = D;
+            eqGains.alloc((size_t)nInst * eqD * SAF_MAXCH * 136);
+            zbuf.alloc((size_t)eqD * nInst * SAF_MAXCH * Hmax * SAF_HOP, true);
+            std::fill(eqDirty.begin(), eqDirty.end(), 1);
+            if (!eqUni.p) {
+                eqUni.alloc((size_t)nInst * SAF_MAXCH); Mfrag.alloc((size_t)nInst * 2 * 64 * 64); zerosI.alloc((size_t)nInst * maxFrames);
+                stageG.ensure((size_t)2 * SAF_MAXCH * 136); stageM.ensure((size_t)2 * 64 * 64); stageU.ensure(SAF_MAXCH);
+                for (int i = 0; i < 2; i++) zsyn[i].alloc((size_t)2 * nInst * nSH * SAF_SYN_HIST * 256);
+            }
+            (void)oldD;     /* zsyn holds both outputs from the start: a pipeline that goes from one dense matrix to two keeps z_0's history, z_1's starts from zero */
+        }
+    }
+    /* afSTFT_clearBuffers for the whole pipeline (ambi_dec.c:218,225) */
+    void clear_state()
+    {
+        st.clear();
+        for (int i = 0; i < 2; i++) zsyn[i].zero();
+        synDomain = DOM_NONE;
+    }
+    /* ... and for one instance (its codec was re-initialised: ambi_dec_initCodec ends with afSTFT_clearBuffers) */
+    void clear_instance(int i)
+    {
+        const size_t na = (size_t)nSH * SAF_ANA_HIST * SAF_HOP, ns = (size_t)(bin ? 2 : nLS) * SAF_SYN_HIST * 256, nz = (size_t)nSH * SAF_SYN_HIST * 256;
+        HIP_CHECK(hipMemsetAsync(st.ana[st.anaPar].p + i * na, 0, na * sizeof(float), stream()));
+        HIP_CHECK(hipMemsetAsync(st.syn[st.synPar].p + i * ns, 0, ns * sizeof(float), stream()));
+        if (zsyn[0].p)
+            for (int d = 0; d < 2; d++) HIP_CHECK(hipMemsetAsync(zsyn[zsynPar].p + ((size_t)d * nInst + i) * nz, 0, nz * sizeof(float), stream()));
+    }
+
+    /* tables of the equaliser path for the instances whose parameters changed (called after refresh()) */
+    void refresh_eq(int mode)
+    {
+        int D = 1;
+        for (int i = 0; i < nInst; i++) {
+            AmbiDec* p = inst[i];
+            if (eqDirty[i]) {
+                const std::vector<float>& M0 = p->M_dec[0][p->masterOrder - 1];
+                const std::vector<float>& M1 = p->M_dec[1][p->masterOrder - 1];
+                eqTwo[i] = !(M0.size() == M1.size() && memcmp(M0.data(), M1.data(), M0.size() * sizeof(float)) == 0);
+            }
+            if (eqTwo[i]) D = 2;
+        }
+        ensure_eq_buffers(D);
+        const bool force = mode == 2;
+        if (force != mode2Shadow) { std::fill(eqDirty.begin(), eqDirty.end(), 1); mode2Shadow = force; }
+        for (int i = 0; i < nInst; i++) {
+            if (!eqDirty[i]) continue;
+            AmbiDec* p = inst[i];
+            const Shadow& s = shadow[i];
+            HIP_CHECK(hipStreamSynchronize(stream()));       /* staging buffers may still be in flight */
+            /* w_{d,n}[k] = M_norm_{d,n} * (max-rE ? a_n[k] : 1) for k < (n+1)^2 (ambi_dec.c:524-539) */
+            float wtab[NUM_DECODERS][SAF_MAX_ORDER][SAF_MAXCH];
+            memset(wtab, 0, sizeof(wtab));
+            for (int d = 0; d < NUM_DECODERS; d++)
+                for (int n = 1; n <= p->masterOrder; n++) {
+                    std::vector<float> a_n; maxre_weights(n, a_n);
+                    const float msc = p->M_norm[d][n - 1][s.eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
+                    for (int k = 0; k < ORDER2NSH(n); k++) wtab[d][n - 1][k] = (s.rE[d] ? a_n[k] : 1.0f) * msc;
+                }
+            float* G = stageG.p; int* U = stageU.p;
+            memset(G, 0, sizeof(float) * (size_t)eqD * SAF_MAXCH * 136);
+            for (int ch = 0; ch < SAF_MAXCH; ch++) {
+                bool uniform = true;
+                for (int band = 0; band < SAF_NBANDS; band++) {
+                    const int mi = s.b2m[band], d = mi / SAF_MAX_ORDER, n = mi % SAF_MAX_ORDER;
+                    const float wv = wtab[d][n][ch];
+                    if (eqD == 1) G[(size_t)ch * 136 + band] = wv;
+                    else G[((size_t)d * SAF_MAXCH + ch) * 136 + band] = wv;
+                }
+                for (int d = 0; d < eqD; d++)
+                    for (int band = 1; band < SAF_NBANDS; band++)
+                        uniform = uniform && G[((size_t)d * SAF_MAXCH + ch) * 136 + band] == G[((size_t)d * SAF_MAXCH + ch) * 136];
+                U[ch] = uniform && !force ? 1 : 0;
+            }
+            HIP_CHECK(hipMemcpyAsync(eqGains.p + (size_t)i * eqD * SAF_MAXCH * 136, G, sizeof(float) * (size_t)eqD * SAF_MAXCH * 136, hipMemcpyHostToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(eqUni.p + (size_t)i * SAF_MAXCH, U, sizeof(int) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
+            /* the dense decoders: the order-N matrices without max-rE / normalisation (ambi_dec.c:283-288), zero-padded */
+            std::vector<float> A(64 * 64);
+            const int nSHo = ORDER2NSH(p->masterOrder);
+            for (int d = 0; d < NUM_DECODERS; d++) {
+                std::fill(A.begin(), A.end(), 0.0f);
+                const std::vector<float>& M = p->M_dec[d][p->masterOrder - 1];
+                for (int l = 0; l < p->nLoudpkrs; l++) for (int k = 0; k < nSHo; k++) A[l * 64 + k] = M[(size_t)l * nSHo + k];
+                pack_A(A.data(), stageM.p + (size_t)d * 64 * 64);
+            }
+            HIP_CHECK(hipMemcpyAsync(Mfrag.p + (size_t)i * 2 * 64 * 64, stageM.p, sizeof(float) * 2 * 64 * 64, hipMemcpyHostToDevice, stream()));
+            HIP_CHECK(hipStreamSynchronize(stream()));
+            eqDirty[i] = 0;
+        }
     }
 
     /* push per-instance tables whose inputs changed since the previous call (parameters are
@@ -182,8 +291,9 @@ struct DecPipeline {
                 HIP_CHECK(hipMemcpyAsync(Afrag.p + (size_t)i * NMAT * 64 * 64, stageA.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream()));
                 if (bin) { HIP_CHECK(hipMemcpyAsync(Arow.p + (size_t)i * NMAT * 64 * 64, stageArow.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream())); foldDirty = true; }
                 HIP_CHECK(hipStreamSynchronize(stream()));
+                if (s.epoch != ~0ull && s.epoch != p->codecEpoch) clear_instance(i);      /* re-initialised codec: ambi_dec_initCodec clears the filterbank (ambi_dec.c:218,225) */
                 s.epoch = p->codecEpoch; s.rE[0] = rE[0]; s.rE[1] = rE[1]; s.eq[0] = eq[0]; s.eq[1] = eq[1];
-                s.b2mValid = false; s.norm = -1; tdDirty[i] = 1;
+                s.b2mValid = false; s.norm = -1; eqDirty[i] = 1;
             }
             int b2m[SAF_NBANDS];
             for (int band = 0; band < SAF_NBANDS; band++) {
@@ -197,7 +307,7 @@ struct DecPipeline {
                 memcpy(stageI.p, b2m, sizeof(b2m));
                 HIP_CHECK(hipMemcpyAsync(band2mat.p + (size_t)i * SAF_NBANDS, stageI.p, sizeof(b2m), hipMemcpyHostToDevice, stream()));
                 HIP_CHECK(hipStreamSynchronize(stream()));
-                memcpy(s.b2m, b2m, sizeof(b2m)); s.b2mValid = true; foldDirty = true; tdDirty[i] = 1;
+                memcpy(s.b2m, b2m, sizeof(b2m)); s.b2mValid = true; foldDirty = true; eqDirty[i] = 1;
             }
             if (s.norm != (int)p->norm || s.chOrd != (int)p->chOrdering) {
                 /* input conventions -> ACN/N3D (ambi_dec.c:500-511, saf_hoa.c:40-116) as a gather map + row scale */
@@ -219,60 +329,8 @@ struct DecPipeline {
                 HIP_CHECK(hipMemcpyAsync(chMap.p + (size_t)i * SAF_MAXCH, map, sizeof(int) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
                 HIP_CHECK(hipMemcpyAsync(chScale.p + (size_t)i * SAF_MAXCH, sc, sizeof(float) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
                 HIP_CHECK(hipStreamSynchronize(stream()));
-                s.norm = (int)p->norm; s.chOrd = (int)p->chOrdering; tdDirty[i] = 1;
+                s.norm = (int)p->norm; s.chOrd = (int)p->chOrdering;
             }
-            if (tdDirty[i] && !bin) {
-                /* time-domain form of the decode: possible when all 133 bands select the same (decoder, order) matrix */
-                /* (the two decoders are separate entries even when they were designed identically: compare contents) */
-                auto eff = [&](int mi, std::vector<float>& E) {
-                    const int d = mi / SAF_MAX_ORDER, n = mi % SAF_MAX_ORDER + 1, nSHo = ORDER2NSH(n);
-                    const std::vector<float>& M = rE[d] ? p->M_dec_maxrE[d][n - 1] : p->M_dec[d][n - 1];
-                    const float msc = p->M_norm[d][n - 1][eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
-                    E.assign(64 * 64, 0.0f);
-                    for (int l = 0; l < p->nLoudpkrs; l++) for (int k = 0; k < nSHo; k++) E[l * 64 + k] = M[(size_t)l * nSHo + k] * msc;
-                };
-                int m = s.b2m[0];
-                {
-                    std::vector<float> E0, E1;
-                    bool seen[NMAT] = { false };
-                    seen[m] = true;
-                    for (int band = 1; band < SAF_NBANDS && m >= 0; band++) {
-                        const int mb = s.b2m[band];
-                        if (seen[mb]) continue;
-                        seen[mb] = true;
-                        if (E0.empty()) eff(m, E0);
-                        eff(mb, E1);
-                        if (memcmp(E0.data(), E1.data(), sizeof(float) * 64 * 64) != 0) m = -1;
-                    }
-                }
-                tdMat[i] = m;
-                if (m >= 0) {
-                    HIP_CHECK(hipStreamSynchronize(stream()));
-                    const int d = m / SAF_MAX_ORDER, n = m % SAF_MAX_ORDER + 1, nSHo = ORDER2NSH(n);
-                    const std::vector<float>& M = rE[d] ? p->M_dec_maxrE[d][n - 1] : p->M_dec[d][n - 1];
-                    const float msc = p->M_norm[d][n - 1][eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
-                    /* x_acn[j] = scale[j] * x_in[map[j]]  ->  column map[j] of the folded matrix collects A[:, j] * scale[j] */
-                    int map[SAF_MAXCH]; float sc[SAF_MAXCH];
-                    for (int ch = 0; ch < SAF_MAXCH; ch++) { map[ch] = ch; sc[ch] = 1.0f; }
-                    if (p->chOrdering == CH_FUMA) { map[1] = 2; map[2] = 3; map[3] = 1; for (int ch = 4; ch < SAF_MAXCH; ch++) map[ch] = -1; }
-                    if (p->norm == NORM_SN3D) { for (int o = 0; o <= p->masterOrder; o++) for (int ch = o * o; ch < ORDER2NSH(o); ch++) sc[ch] = sqrtf(2.0f * (float)o + 1.0f); }
-                    else if (p->norm == NORM_FUMA) { sc[0] = sqrtf(2.0f); for (int ch = 1; ch < 4; ch++) sc[ch] = sqrtf(3.0f); }
-                    std::vector<float> A(64 * 64, 0.0f);
-                    for (int l = 0; l < p->nLoudpkrs; l++)
-                        for (int k = 0; k < nSHo; k++) if (map[k] >= 0) A[l * 64 + map[k]] += (M[(size_t)l * nSHo + k] * msc) * sc[k];
-                    pack_A(A.data(), stageT.p);
-                    HIP_CHECK(hipMemcpyAsync(AfragT.p + (size_t)i * 64 * 64, stageT.p, sizeof(float) * 64 * 64, hipMemcpyHostToDevice, stream()));
-                    HIP_CHECK(hipStreamSynchronize(stream()));
-                }
-                tdDirty[i] = 0; tdTableDirty = true;
-            }
-        }
-        if (tdTableDirty && !bin) {
-            HIP_CHECK(hipStreamSynchronize(stream()));
-            for (int i = 0; i < nInst; i++) stageTi.p[i] = tdMat[i] < 0 ? 0 : tdMat[i];
-            HIP_CHECK(hipMemcpyAsync(b2mT.p, stageTi.p, sizeof(int) * nInst, hipMemcpyHostToDevice, stream()));
-            HIP_CHECK(hipStreamSynchronize(stream()));
-            tdTableDirty = false;
         }
     }
 
@@ -321,41 +379,48 @@ struct DecPipeline {
             }
         }
         const int H = nFrames * T;
-        bool td = !bin && g_ambi_dec_time_domain && nChPresent >= nSH && ((in_inst | in_frame | in_ch) & 3) == 0 && (((uintptr_t)d_in) & 15) == 0 &&
-                  ((out_inst | out_frame | out_ch) & 1) == 0 && (((uintptr_t)d_out) & 7) == 0;
-        for (int i = 0; i < nInst && td; i++) td = tdMat[i] >= 0;
-        if (td) {
-            /* band-independent decoding (every band uses the same matrix): y = A x over the 15 history hops (already in the
-             * ACN/N3D convention) and over the new blocks (conventions folded into the matrix), then the transform-free
-             * analysis -> synthesis of y.  Both states of AfState advance exactly as in the transform path. */
-            const long long yCh = (long long)(SAF_ANA_HIST + Hmax) * SAF_HOP, yInst = (long long)SAF_MAXCH * yCh;
-            BandGemmLaunch gh{};
-            gh.X = st.ana[st.anaPar].p; gh.x_inst = (long long)nSH * SAF_ANA_HIST * SAF_HOP; gh.x_band = 0; gh.x_row = SAF_ANA_HIST * SAF_HOP;
-            gh.Y = ybuf.p; gh.y_inst = yInst; gh.y_band = 0; gh.y_row = yCh;
-            gh.Afrag = Afrag.p; gh.a_inst = (long long)NMAT * 64 * 64; gh.band2mat = b2mT.p;
-            gh.nBands = 1; gh.nInst = nInst; gh.N = SAF_ANA_HIST * SAF_HOP; gh.nRowsX = nSH;
-            launch_band_gemm(gh);
+        const int mode = g_ambi_dec_time_domain;
+        /* the time-domain GEMM writes the caller's block with 16-byte stores */
+        const bool eq = !bin && mode != 0 && synDomain != DOM_LS &&
+                        ((out_inst | out_frame | out_ch) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0;
+        if (eq) {
+            refresh_eq(mode);
+            const long long zCh = (long long)Hmax * SAF_HOP, zInst = (long long)SAF_MAXCH * zCh, zD = (long long)nInst * zInst;
+            const long long synD = (long long)nInst * nSH * SAF_SYN_HIST * 256;
+            EqLaunch q{};
+            q.in = d_in; q.in_inst = in_inst; q.in_ch = in_ch; q.in_frame = in_frame; q.hopsPerFrame = T; q.nChIn = nChPresent;
+            q.hist_rd = st.ana[st.anaPar].p; q.hist_wr = st.ana[st.anaPar ^ 1].p;
+            q.ch_scale = chScale.p; q.ch_map = chMap.p;
+            q.gains = eqGains.p; q.uniform = eqUni.p; q.D = eqD;
+            q.z = zbuf.p; q.z_d = zD; q.z_inst = zInst; q.z_ch = zCh;
+            q.syn_rd = zsyn[zsynPar].p; q.syn_wr = zsyn[zsynPar ^ 1].p; q.syn_d = synD;
+            q.nCh = nSH; q.nInst = nInst; q.H = H;
+            launch_eq(q);
+            st.anaPar ^= 1; zsynPar ^= 1;
+            /* out = M_0 z_0 (+ M_1 z_1): "band" = block, columns = the F samples of the block */
             BandGemmLaunch gn{};
-            gn.X = d_in; gn.x_inst = in_inst; gn.x_band = in_frame; gn.x_row = in_ch;
-            gn.Y = ybuf.p + SAF_ANA_HIST * SAF_HOP; gn.y_inst = yInst; gn.y_band = F; gn.y_row = yCh;
-            gn.Afrag = AfragT.p; gn.a_inst = 64 * 64; gn.band2mat = zerosI.p;
-            gn.nBands = nFrames; gn.nInst = nInst; gn.N = F; gn.nRowsX = nChPresent < SAF_MAXCH ? nChPresent : SAF_MAXCH;
+            gn.X = zbuf.p; gn.x_inst = zInst; gn.x_band = F; gn.x_row = zCh; gn.nTerms = eqD; gn.x_term = zD;
+            gn.Y = d_out; gn.y_inst = out_inst; gn.y_band = out_frame; gn.y_row = out_ch; gn.nRowsY = nLS;
+            gn.Afrag = Mfrag.p; gn.a_inst = 2 * 64 * 64; gn.band2mat = zerosI.p;
+            gn.nBands = nFrames; gn.nInst = nInst; gn.N = F; gn.nRowsX = nSH;
             launch_band_gemm(gn);
-            AnaHistLaunch ah{};
-            ah.in = d_in; ah.in_inst = in_inst; ah.in_ch = in_ch; ah.in_frame = in_frame; ah.hopsPerFrame = T; ah.nChIn = nChPresent;
-            ah.hist_rd = st.ana[st.anaPar].p; ah.hist_wr = st.ana[st.anaPar ^ 1].p; ah.ch_scale = chScale.p; ah.ch_map = chMap.p; ah.tab_stride = SAF_MAXCH;
-            ah.nCh = nSH; ah.nInst = nInst; ah.H = H;
-            launch_ana_hist_update(ah);
-            st.anaPar ^= 1;
-            RoundtripLaunch r{};
-            r.y = ybuf.p; r.y_inst = yInst; r.y_ch = yCh;
-            r.out = d_out; r.out_inst = out_inst; r.out_ch = out_ch; r.out_frame = out_frame; r.hopsPerFrame = T;
-            r.syn_rd = st.syn[st.synPar].p; r.syn_wr = st.syn[st.synPar ^ 1].p;
-            r.nCh = nLS; r.nInst = nInst; r.H = H;
-            launch_roundtrip(r);
-            st.synPar ^= 1;
+            synDomain = DOM_SH; lastPath = 1;
             return;
         }
+        ensure_transform_buffers();
+        if (synDomain == DOM_SH) {
+            /* the overlap-add history of the equaliser path, taken to the loudspeaker domain: st.syn = sum_d M_d zsyn_d */
+            const long long fr = (long long)SAF_SYN_HIST * 256;
+            BandGemmLaunch gc{};
+            gc.X = zsyn[zsynPar].p; gc.x_inst = (long long)nSH * fr; gc.x_band = 0; gc.x_row = fr; gc.nTerms = eqD; gc.x_term = (long long)nInst * nSH * fr;
+            gc.Y = st.syn[st.synPar].p; gc.y_inst = (long long)nLS * fr; gc.y_band = 0; gc.y_row = fr; gc.nRowsY = nLS;
+            gc.Afrag = Mfrag.p; gc.a_inst = 2 * 64 * 64; gc.band2mat = zerosI.p;
+            gc.nBands = 1; gc.nInst = nInst; gc.N = (int)fr; gc.nRowsX = nSH;
+            launch_band_gemm(gc);
+            for (int i = 0; i < 2; i++) zsyn[i].zero();
+        }
+        if (!bin) synDomain = DOM_LS;
+        lastPath = 0;
         AnaLaunch a{};
         a.in = d_in; a.in_inst = in_inst; a.in_ch = in_ch; a.in_frame = in_frame; a.hopsPerFrame = T; a.nChIn = nChPresent;
         a.hist_rd = st.ana[st.anaPar].p; a.hist_wr = st.ana[st.anaPar ^ 1].p;
@@ -413,7 +478,7 @@ using namespace saf;
 
 extern "C" {
 
-void saf_hip_ambi_dec_setTimeDomainPath(int enable) { g_ambi_dec_time_domain = enable ? 1 : 0; }
+void saf_hip_ambi_dec_setTimeDomainPath(int mode) { g_ambi_dec_time_domain = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 int saf_hip_ambi_dec_getTimeDomainPath(void) { return g_ambi_dec_time_domain; }
 
 void saf_hip_ambi_dec_setFrameSize(int frameSize)
@@ -726,7 +791,9 @@ void saf_hip_ambi_dec_batch_destroy(void** const phBatch)
     delete (DecPipeline*)*phBatch;
     *phBatch = nullptr;
 }
-void saf_hip_ambi_dec_batch_clear(void* const hBatch) { ((DecPipeline*)hBatch)->st.clear(); }
+void saf_hip_ambi_dec_batch_clear(void* const hBatch) { ((DecPipeline*)hBatch)->clear_state(); }
+int saf_hip_ambi_dec_batch_lastPath(void* const hBatch) { return ((DecPipeline*)hBatch)->lastPath; }
+int saf_hip_ambi_dec_lastPath(void* const hAmbi) { AmbiDec* p = (AmbiDec*)hAmbi; return p->pipe ? p->pipe->lastPath : -1; }
 void saf_hip_ambi_dec_batch_process(void* const hBatch,
                                     const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride,
                                     float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride,

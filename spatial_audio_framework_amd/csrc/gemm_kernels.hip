@@ -102,6 +102,7 @@ __global__ __launch_bounds__(128, 1) void band_gemm_kernel(GemmArgs a)
             for (int r = 0; r < 16; r++) {
                 const int row = rt * 32 + tile_row(r, lane);
                 const float4 v = make_float4(t.c[0][r], t.c[1][r], t.c[2][r], t.c[3][r]);
+                if (row >= g.nRowsY) continue;
                 if (FULL) *reinterpret_cast<float4*>(Y + (long long)row * g.y_row) = v;
                 else store4_bounded(Y + (long long)row * g.y_row, v, nValid);
             }
@@ -117,6 +118,70 @@ __global__ __launch_bounds__(128, 1) void band_gemm_kernel(GemmArgs a)
             if (u + 2 < u1) { pA = unit_ptr(u + 2, bandA, colA); gemm_load_tile<FULL>(bA, pA, g.x_row, g.N - colA, kh, g.nRowsX); }
             compute_store(bB, bandB, colB);
         }
+    }
+}
+
+/* Two-term variant:  Y = A_0 X_0 + A_1 X_1  (the time-domain decode after the filterbank equaliser when the two decoders
+ * of ambi_dec are different matrices: out = M_0 z_0 + M_1 z_1).  Same tile and register budget; the two operand tiles of a
+ * unit take the places of the two units in flight of the one-term kernel: term 1 is in flight under the MFMAs of term 0,
+ * the next unit's term 0 under those of term 1. */
+__global__ __launch_bounds__(128, 1) void band_gemm2_kernel(GemmArgs a)
+{
+    constexpr bool FULL = true;          /* complete column tiles only (N % 128 == 0) */
+    const BandGemmLaunch& g = a.g;
+    const int inst = blockIdx.y;
+    const int lane = threadIdx.x & 63, rt = threadIdx.x >> 6;
+    const int kh = lane >> 5;
+    const int u0 = blockIdx.x * a.G;
+    const int u1 = min(u0 + a.G, a.unitsPerInst);
+    if (u0 >= u1) return;
+    const float* Xi = g.X + (long long)inst * g.x_inst;
+    float* Yi = g.Y + (long long)inst * g.y_inst;
+    const float* Ai = g.Afrag + (long long)inst * g.a_inst + (long long)rt * 32 * 64 + lane;
+    const int* b2m = g.band2mat + inst * g.nBands;
+
+    float av0[32], av1[32];
+    int curMat = -1;
+    float4 bA[32], bB[32];
+    auto unit_ptr = [&](int u, int& band, int& col) {
+        band = u / a.nColTiles; const int ct = u - band * a.nColTiles;
+        col = ct * 128 + 4 * (lane & 31);
+        return Xi + (long long)band * g.x_band + col;
+    };
+    int band, col;
+    const float* p = unit_ptr(u0, band, col);
+    gemm_load_tile<FULL>(bA, p, g.x_row, g.N - col, kh, g.nRowsX);
+    gemm_load_tile<FULL>(bB, p + g.x_term, g.x_row, g.N - col, kh, g.nRowsX);
+    for (int u = u0; u < u1; u++) {
+        const int mat = b2m[band];
+        if (mat != curMat) {
+#pragma unroll
+            for (int s = 0; s < 32; s++) { av0[s] = Ai[(long long)mat * 2 * 32 * 64 + s * 64]; av1[s] = Ai[(long long)(mat + 1) * 2 * 32 * 64 + s * 64]; }
+            curMat = mat;
+        }
+        Tile128 t;
+        tile_zero(t);
+#pragma unroll
+        for (int i = 0; i < 32; i++) tile_step(t, av0[i], bA[i]);
+        int bandN = band, colN = col;
+        const float* pN = p;
+        if (u + 1 < u1) { pN = unit_ptr(u + 1, bandN, colN); gemm_load_tile<FULL>(bA, pN, g.x_row, g.N - colN, kh, g.nRowsX); }
+#pragma unroll
+        for (int i = 0; i < 32; i++) tile_step(t, av1[i], bB[i]);
+        if (u + 1 < u1) gemm_load_tile<FULL>(bB, pN + g.x_term, g.x_row, g.N - colN, kh, g.nRowsX);
+        const int nValid = g.N - col;
+        if (nValid > 0) {
+            float* Y = Yi + (long long)band * g.y_band + col;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = rt * 32 + tile_row(r, lane);
+                const float4 v = make_float4(t.c[0][r], t.c[1][r], t.c[2][r], t.c[3][r]);
+                if (row >= g.nRowsY) continue;
+                if (FULL) *reinterpret_cast<float4*>(Y + (long long)row * g.y_row) = v;
+                else store4_bounded(Y + (long long)row * g.y_row, v, nValid);
+            }
+        }
+        band = bandN; col = colN; p = pN;
     }
 }
 
@@ -137,8 +202,13 @@ void launch_band_gemm(const BandGemmLaunch& g)
     a.G = G;
     dim3 grid((a.unitsPerInst + G - 1) / G, g.nInst);
     KernelTimer kt("band_gemm");
-    if (g.N % 128 == 0) hipLaunchKernelGGL(band_gemm_kernel<true>, grid, dim3(128), 0, stream(), a);
-    else                hipLaunchKernelGGL(band_gemm_kernel<false>, grid, dim3(128), 0, stream(), a);
+    if (g.nTerms == 2) {
+        if (g.x_term & 3) SAF_FATAL("band gemm: the term stride must be a multiple of 4 floats");
+        if (g.N % 128 != 0) SAF_FATAL("band gemm: the two-term form needs N to be a multiple of 128");
+        hipLaunchKernelGGL(band_gemm2_kernel, grid, dim3(128), 0, stream(), a);
+    } else if (g.nTerms != 1) SAF_FATAL("band gemm: 1 or 2 terms");
+    else if (g.N % 128 == 0) hipLaunchKernelGGL(band_gemm_kernel<true>, grid, dim3(128), 0, stream(), a);
+    else                     hipLaunchKernelGGL(band_gemm_kernel<false>, grid, dim3(128), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -169,6 +169,23 @@ struct AnaHistLaunch {
 };
 void launch_ana_hist_update(const AnaHistLaunch& a);
 
+/* ---- afSTFT analysis -> real gain per (channel, band) -> afSTFT synthesis in one kernel (eq_kernels.hip) ----
+ * z_d[ch] = synthesis( gains[d][ch][band] (.) analysis(x[ch]) ) for d < D (1 or 2) and every channel; hybrid mode, normal
+ * delay.  Input addressing, conventions (ch_map / ch_scale) and the input history are those of AnaLaunch; the frame
+ * history (9 synthesised frames per channel and output d) has the layout of SynLaunch::hist per d. */
+struct EqLaunch {
+    const float* in; long long in_inst, in_ch, in_frame; int hopsPerFrame, nChIn;
+    const float* hist_rd; float* hist_wr;          /* [inst][nCh][15][128] */
+    const float* ch_scale; const int* ch_map;      /* [inst][64] or null */
+    const float* gains;                            /* [inst][D][64][136] (bands 133..135 unused) */
+    const int* uniform;                            /* [inst][64] 1: the gains of this channel are the same in every band (for every d), or null */
+    int D;
+    float* z; long long z_d, z_inst, z_ch;         /* z[d*z_d + inst*z_inst + ch*z_ch + hop*128 + n] */
+    const float* syn_rd; float* syn_wr; long long syn_d;      /* [d][inst][nCh][9][256] */
+    int nCh, nInst, H;
+};
+void launch_eq(const EqLaunch& e);
+
 /* ---- band-batched real GEMM on MFMA (gemm_kernels.hip) ----
  * For every (inst, band): Y[64 x N] = A[mat(inst,band)][64 x 64] * X[64 x N], N = 2*H floats
  * (interleaved re/im of H time slots).  A is stored in MFMA fragment order, see pack_A(). */
@@ -180,6 +197,9 @@ struct BandGemmLaunch {
     const int* band2mat;           /* [nInst][nBands] */
     int nBands, nInst, N;
     int nRowsX = 64;               /* rows physically present in X: higher rows re-read the last one (their matrix columns are zero) */
+    /* nTerms = 2:  Y = A_0 X_0 + A_1 X_1  with X_1 = X + x_term and A_1 = the matrix after A_0 (Afrag + 4096 floats) */
+    int nTerms = 1; long long x_term = 0;
+    int nRowsY = 64;               /* rows of Y that exist: rows beyond are computed (against zero matrix rows) but not stored */
 };
 void launch_band_gemm(const BandGemmLaunch& g);
 void pack_A(const float* A /* [64][64] row-major, zero padded */, float* Afrag /* [2][32][64] */);

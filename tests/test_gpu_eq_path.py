@@ -1,0 +1,190 @@
+"""The equaliser path of ambi_dec (eq_kernels.hip + one time-domain GEMM) against the CPU oracle and against the
+three-kernel transform path — needs an MI355X:  python -m pytest tests -m gpu
+
+Every per-band matrix of ambi_dec_process (examples/src/ambi_dec/ambi_dec.c:518-540) = dense decoder x diagonal of
+per-channel weights; the equaliser path applies the diagonal inside a per-channel filterbank (spectra stay on chip) and
+the dense part as one time-domain GEMM.  Tolerance: 1e-5 relative RMS (BASELINE north star); measured ~3e-7.
+"""
+import numpy as np
+import pytest
+
+from util import frames, relrms
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture()
+def path(saf):
+    from spatial_audio_framework_amd._lib import load
+    L = load()
+    yield L.saf_hip_ambi_dec_setTimeDomainPath
+    L.saf_hip_ambi_dec_setTimeDomainPath(1)
+
+
+def make(cls, F, order, preset, m0, m1, norm=1, chord=1, orders=None, **kw):
+    d = cls(F)
+    d.setNormType(norm); d.setChOrder(chord); d.setMasterDecOrder(order); d.setOutputConfigPreset(preset)
+    d.setDecMethod(0, m0); d.setDecMethod(1, m1)
+    d.initCodec(); d.init(48000); d.setDecOrderAllBands(order)
+    if orders is not None:
+        for b, o in enumerate(orders):
+            d.setDecOrder(int(o), b)
+    for k, v in kw.items():
+        getattr(d, k)(*v)
+    return d
+
+
+def run(dec, x, nOut, F):
+    return np.concatenate([dec.process(np.ascontiguousarray(x[:, i * F:(i + 1) * F]), nOut) for i in range(x.shape[1] // F)], 1)
+
+
+def band_orders(order, seed):
+    """an arbitrary order per band (what setDecOrder / the microphone presets produce): every order 1..N appears"""
+    rng = np.random.default_rng(seed)
+    o = rng.integers(1, order + 1, 133)
+    o[:order] = np.arange(1, order + 1)
+    return o
+
+
+CASES = [
+    # F, order, preset, m0, m1, norm, chord, per-band orders?, extra settings
+    (512, 7, 29, 1, 1, 1, 1, False, {}),                                              # headline: one matrix everywhere
+    (512, 7, 29, 1, 1, 2, 1, True, {}),                                               # same decoders, every band its own order
+    (256, 5, 28, 1, 3, 2, 1, False, dict(setTransitionFreq=(1200.0,))),               # SAD below / EPAD above: two dense matrices
+    (256, 5, 28, 4, 2, 1, 1, True, dict(setDecNormType=(0, 1), setDecEnableMaxrE=(1, 0))),   # AllRAD / MMD, orders, amplitude norm, no max-rE above
+    (128, 3, 21, 3, 3, 2, 1, True, dict(setDecEnableMaxrE=(0, 0), setTransitionFreq=(700.0,))),
+    (128, 1, 3, 1, 4, 3, 2, False, {}),                                               # FuMa first order into a 2-D layout
+    (1024, 4, 24, 2, 2, 1, 1, True, {}),
+]
+
+
+@pytest.mark.parametrize("F,order,preset,m0,m1,norm,chord,perband,kw", CASES)
+def test_equaliser_path_vs_oracle_and_transform_path(saf, orc, path, F, order, preset, m0, m1, norm, chord, perband, kw):
+    nSH = (order + 1) ** 2
+    orders = band_orders(order, F + order) if perband else None
+    nB = 10 if F >= 256 else 30
+    x = frames(900 + F + order, nSH, nB * F)
+    o = make(orc.AmbiDec, F, order, preset, m0, m1, norm, chord, orders, **kw)
+    nLS = o.getNumLoudspeakers()
+    yo = run(o, x, nLS, F)
+    assert np.abs(yo).max() > 0.01
+    outs = {}
+    for mode in (1, 2, 0):
+        path(mode)
+        g = make(saf.AmbiDec, F, order, preset, m0, m1, norm, chord, orders, **kw)
+        outs[mode] = run(g, x, nLS, F)
+        assert g.lastPath() == (0 if mode == 0 else 1)
+        assert relrms(outs[mode], yo) < TOL and relrms(outs[mode], yo) < 3e-6, mode
+    assert relrms(outs[1], outs[0]) < 3e-6 and relrms(outs[2], outs[0]) < 3e-6
+
+
+def test_equaliser_path_parameter_changes_and_switch_to_transform(saf, orc, path):
+    """Parameters changed between blocks act on the spectra of the following blocks exactly as in the reference (snapshot at
+    block start, ambi_dec.c:479-488) — also when they flip channels between 'uniform' and 'needs the transforms'; then the
+    pipeline is switched to the transform path mid-stream: the SH-domain overlap-add history is converted (exact)."""
+    F, order, preset = 256, 5, 28
+    x = frames(77, 36, 24 * F)
+
+    def go(cls, sched):
+        d = make(cls, F, order, preset, 1, 3, 2)
+        ys = []
+        for b in range(24):
+            if b == 4: d.setDecOrderAllBands(3)
+            if b == 7: d.setDecEnableMaxrE(0, 0); d.setDecNormType(1, 1)
+            if b == 10:
+                for band in range(20, 90): d.setDecOrder(2 + band % 3, band)
+            if b == 13: d.setTransitionFreq(1900.0)
+            if b == 16: d.setDecOrderAllBands(5)
+            if sched is not None: path(sched[b])
+            ys.append(d.process(np.ascontiguousarray(x[:, b * F:(b + 1) * F]), 49))
+        return np.concatenate(ys, 1), d
+
+    yo, _ = go(orc.AmbiDec, None)
+    for sched in ([1] * 24, [2] * 24, [1] * 9 + [0] * 15, [2] * 14 + [0] * 5 + [1] * 5):
+        yg, d = go(saf.AmbiDec, sched)
+        assert relrms(yg, yo) < 3e-6, sched
+        assert d.lastPath() == (0 if 0 in sched else 1)      # a pipeline that ran the transform path stays on it
+
+
+def test_equaliser_path_missing_and_extra_channels(saf, orc, path):
+    """fewer inputs than SH channels (the rest are zero) and more outputs asked than loudspeakers (zero-filled)"""
+    F, order = 128, 3
+    x = frames(31, 11, 20 * F)                       # 11 of 16 inputs
+    for mode in (1, 2):
+        path(mode)
+        g, o = make(saf.AmbiDec, F, order, 26, 1, 3, orders=band_orders(3, 5)), make(orc.AmbiDec, F, order, 26, 1, 3, orders=band_orders(3, 5))
+        yg, yo = run(g, x, 20, F), run(o, x, 20, F)
+        assert g.lastPath() == 1
+        assert relrms(yg, yo) < 3e-6 and not yg[16:].any()
+
+
+def test_equaliser_path_batch_split_invariance_and_strides(saf, orc, path):
+    """batched device entry: instances with different decoders / orders; the same stream cut into different calls gives
+    bit-identical output; channel-major and frame-major layouts"""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    F, order, nI, nF = 512, 7, 4, 6
+    cfgs = [(1, 1, 1, None), (3, 2, 2, band_orders(7, 1)), (4, 1, 1, band_orders(7, 2)), (1, 1, 2, band_orders(7, 3))]
+    x = np.stack([frames(500 + i, nF * 64, 512).reshape(nF, 64, 512) for i in range(nI)])
+    d_in = torch.from_numpy(x).cuda()
+    st = (nF * 64 * 512, 64 * 512, 512)
+    res = {}
+    for mode in (1, 2, 0):
+        path(mode)
+        decs = [make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs]
+        for split in ((nF,), (1, 2, 3)):
+            bt = saf.AmbiDecBatch(decs, nF)
+            d_out = torch.zeros(nI, nF, 64, 512, device="cuda")
+            f0 = 0
+            for n in split:
+                bt.process_ptr(d_in[:, f0:].data_ptr(), st, d_out[:, f0:].data_ptr(), st, n)
+                f0 += n
+            torch.cuda.synchronize()
+            assert bt.lastPath() == (0 if mode == 0 else 1)
+            res[(mode, split)] = d_out.cpu().numpy()
+        assert np.array_equal(res[(mode, (nF,))], res[(mode, (1, 2, 3))]), mode
+    orcs = [make(orc.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs]
+    for i in range(nI):
+        yo = np.stack([orcs[i].process(x[i, f], 64) for f in range(nF)])
+        for mode in (1, 2, 0):
+            assert relrms(res[(mode, (nF,))][i], yo) < 3e-6, (mode, i)
+    saf.set_stream(None)
+
+
+def test_equaliser_path_full_size_properties(saf, path):
+    """bench size (256 instances x 64 blocks, every band its own order): linearity, instance independence, split invariance,
+    and agreement with the transform path — the oracle is too slow here"""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    nI, nF = 256, 64
+    orders = band_orders(7, 9)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    a = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+    b = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+    st = (nF * 64 * 512, 64 * 512, 512)
+
+    def go(x, mode, split=None):
+        path(mode)
+        decs = [make(saf.AmbiDec, 512, 7, 29, 1, 1, 1, 1, orders) for _ in range(8)]
+        bt = saf.AmbiDecBatch([decs[i % 8] for i in range(nI)], nF)
+        y = torch.zeros_like(x)
+        f0 = 0
+        for n in (split or (nF,)):
+            bt.process_ptr(x[:, f0:].data_ptr(), st, y[:, f0:].data_ptr(), st, n)
+            f0 += n
+        torch.cuda.synchronize()
+        return y
+
+    ya, yb = go(a, 1), go(b, 1)
+    yab = go(2.0 * a - 0.5 * b, 1)
+    lin = 2.0 * ya - 0.5 * yb
+    assert float((yab - lin).norm() / lin.norm()) < 1e-6
+    assert torch.equal(go(a, 1, split=(1, 31, 32)), ya)
+    a2 = a.clone(); a2[5] = b[5]
+    y2 = go(a2, 1)
+    assert torch.equal(y2[:5], ya[:5]) and torch.equal(y2[6:], ya[6:]) and torch.equal(y2[5], yb[5])
+    del yb, yab, lin, y2, a2
+    yt = go(a, 0)
+    assert float((ya - yt).norm() / yt.norm()) < 3e-6
+    saf.set_stream(None)
