@@ -35,6 +35,17 @@ __device__ __forceinline__ void lds_barrier()
  * slots, whose bases are only 16 banks apart — are spread over all banks instead of colliding 4- to 8-fold. */
 #define SLOT_SG(pos) (((pos) >> 1) & 7)
 
+/* The W128 twiddles of the 8 lanes live in LDS as [p][j] (lane j reads s_tw[p*8 + j]): the 8 lanes of an FFT group read 8
+ * consecutive float2 and all groups of a wave read the same ones (broadcast).  Stored [j][p] the 8 lanes hit 8 different
+ * rows 128 bytes apart = ONE bank pair: an 8-way conflict on each of the 16 twiddle reads of an FFT, which was more than
+ * half of the LDS cycles of the filterbank kernels (tools/probes/lds_probe.hip, profiles/r02_lds_probe.txt). */
+struct TwCol {
+    const float2* p;
+    __device__ __forceinline__ float2 operator[](int i) const { return p[i * 8]; }
+};
+/* fill s_tw[128] ([p][j]) from the device table ([j][p]); call with tid < 128 */
+__device__ __forceinline__ void load_twiddles_pj(float2* s_tw, const float2* g_tw, int tid) { s_tw[(tid & 15) * 8 + (tid >> 4)] = g_tw[tid]; }
+
 template <bool INV, typename TW> __device__ __forceinline__ void fft128_slot(float* slot, int j, const TW& twJ, int sg)
 {
     const int js = j ^ sg;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
     const int T = g.a.hopsPerFrame;
 
     for (int k = tid; k < 129; k += 128 * NCH) s_tw256[k] = g.tw256[k];
-    if (tid < 128) s_twJ[tid] = g.twJ[tid];
+    if (tid < 128) load_twiddles_pj(s_twJ, g.twJ, tid);
 
     /* ---- fold role: thread = (channel of the pair, sample position) ---- */
     const int fc = tid >> 7, fn = tid & 127;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
     /* ---- FFT role: thread = (FFT of the sub-chunk, lane j of its group of 8) ---- */
     const int ff = tid >> 3, fj = tid & 7;
     const int fftC = ff >> 4, fftT = ff & 15;
-    const float2* twJ = s_twJ + fj * 16;
+    const TwCol twJ{ s_twJ + fj };
 
     /* input cursor: element offset of the next non-negative hop inside this instance's input (uniform) */
     int curHop = c0 - SAF_ANA_HIST < 0 ? 0 : c0 - SAF_ANA_HIST;
@@ -316,11 +316,11 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
     const int nSub = (H - hs + SUB - 1) / SUB;
     const bool producer = tid < 128;
     for (int k = tid; k < 129; k += 256) s_tw256[k] = g.tw256[k];
-    if (tid < 128) s_twJ[tid] = g.twJ[tid];
+    if (tid < 128) load_twiddles_pj(s_twJ, g.twJ, tid);
 
     if (producer) {
         const int ff = tid >> 3, fj = tid & 7;                    /* FFT role: 16 FFTs x 8 lanes */
-        const float2* twJ = s_twJ + fj * 16;
+        const TwCol twJ{ s_twJ + fj };
         const float2* inBase = g.s.in + (long long)inst * g.s.in_inst + (long long)ch * g.s.in_ch;
         const unsigned ib32 = (unsigned)g.s.in_band;
         /* spectra loads: uniform 64-bit base + 32-bit byte offset per lane (launch_synthesis checks the extent) */

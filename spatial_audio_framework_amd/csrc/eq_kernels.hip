@@ -23,13 +23,17 @@
  * sub-chunk's folds / spectra / frames live in a ring of 1 KiB LDS slots (one slot = one hop), transformed in place:
  *   1 fold     thread = sample position, sliding 10-hop register window, every input sample read once
  *   2 FFT      8 lanes x 16 points per hop (fft128_slot); bins 1..4 of the new hop -> s_low (hybrid FIR history)
- *   3 special  hybrid bins 1..4 (afSTFT_internal.c:595-619 + the gains of their two half-bands + merge) and DC / Nyquist
- *   4 main     lane = bin pair (k, 128-k) of one slot: real-FFT split, gains, half-complex packing — consecutive
- *              8-byte LDS accesses, conflict-free, in place
- *   5 IFFT     in place
- *   6 OLA      thread = sample position, frame history in registers, output stores
- * Phases 3-6 run three hops behind phases 1-2: the hybrid filter of output hop t needs bins 1..4 of hops t, t-2, t-4,
- * t-6 and everything else of hop t-3.
+ *   3 bins     lane = bin pair (k, 128-k) of one slot: real-FFT split, gains, half-complex packing — consecutive
+ *              8-byte LDS accesses, conflict-free, in place.  The hybrid bins 1..4 (afSTFT_internal.c:595-619 + the gains
+ *              of their two half-bands + merge) and DC / Nyquist are separate items of the same phase: every item reads
+ *              and writes only its own two elements of the slot
+ *   4 IFFT     in place
+ *   5 OLA      thread = sample position, frame history in registers, output stores
+ * Phases 3-5 run three hops behind phases 1-2: the hybrid filter of output hop t needs bins 1..4 of hops t, t-2, t-4,
+ * t-6 and everything else of hop t-3.  Three workgroup barriers per sub-chunk: fold -> FFT (every FFT reads all sample
+ * positions), FFT -> bins (the hybrid filter reads bins of hops transformed by the other wave), IFFT -> OLA.  A wave runs
+ * phases 3 and 4 on the same 8 slots (LDS operations of a wave execute in order: no barrier), and phase 5 -> phase 1 of
+ * the next sub-chunk needs none either: in both a thread touches only the two elements of its own sample position.
  */
 #include "saf_hip_common.h"
 #include "afstft_device.h"
@@ -39,19 +43,24 @@ namespace saf {
 #define ERING 20        /* slots in the ring: 16 new hops + 3 lagged + 1 (a multiple of 4: the four FFT groups of a lane
                          * group stay 16 banks apart across the wrap) */
 #define LOWR  32        /* hops of bins 1..4 kept for the hybrid FIR (power of two >= 16 + 7) */
-#define EQ_OLA 8
+#ifndef EQ_OLA
+#define EQ_OLA 4
+#endif
+#ifndef EQ_MINWAVES
+#define EQ_MINWAVES 3       /* waves per SIMD the one-output kernel is compiled for (168 registers) */
+#endif
 
 struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; };
 
 template <int D>
-__global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
+__global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kernel(EqArgs g)
 {
     __shared__ __attribute__((aligned(16))) float s_ring[ERING * SLOT];
     __shared__ __attribute__((aligned(16))) float s_out1[D > 1 ? SUB * SLOT : 4];      /* frames of the second output */
     __shared__ float2 s_low[LOWR][4];
-    __shared__ float2 s_hyb[D][SUB][4];
     __shared__ float s_gain[D][136];
     __shared__ float2 s_twJ[8 * 16];
+    __shared__ float2 s_twl[8];                              /* e^{-2 pi i k / 256}, k < 8 (bins 1..4) */
 
     const EqLaunch& e = g.e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -59,7 +68,8 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
     const int H = e.H, T = e.hopsPerFrame;
     const bool uni = e.uniform != nullptr && e.uniform[inst * SAF_MAXCH + ch] != 0;
 
-    s_twJ[tid] = g.twJ[tid];
+    load_twiddles_pj(s_twJ, g.twJ, tid);
+    if (tid < 8) s_twl[tid] = g.tw256[tid];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         const float* gsrc = e.gains + (((long long)inst * D + d) * SAF_MAXCH + ch) * 136;
@@ -85,8 +95,7 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
 
     /* ---- FFT role: thread = (hop of the sub-chunk, lane j of its group of 8) ---- */
     const int ff = tid >> 3, fj = tid & 7;
-    const float2* twJ = s_twJ + fj * 16;
-    const float2 Wlow = g.tw256[fj];                        /* e^{-2 pi i j / 256}: lanes 1..4 extract bins 1..4 */
+    const TwCol twJ{ s_twJ + fj };
 
     /* ---- main-pass role: lane = bin pair (k, 128-k), k = lane + 1 ---- */
     const int mk = lane + 1;
@@ -122,13 +131,17 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
         if (i + 1 < H) advance();
     }
     __syncthreads();                                         /* s_gain, s_twJ */
+    /* the gains carry the 1/2 of the real-FFT split and the 1/256 of the inverse transform (1/2 of the packing, 1/128 of
+     * saf_rfft_backward, saf_utility_fft.c:751): powers of two, so nothing changes in the rounding */
+    const float GS = 1.0f / 256.0f;
     float sc[D];
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        gk[d] = 0.5f * s_gain[d][mk < 5 ? 0 : mk + 4];     /* band of bin k >= 5 is k + 4 (bins 1..4 come from s_hyb) */
-        gm[d] = 0.5f * s_gain[d][132 - mk];                 /* band of bin 128 - k */
-        sc[d] = uni ? s_gain[d][0] : 1.0f / 256.0f;         /* frame scale of the overlap-add */
+        gk[d] = 0.5f * GS * s_gain[d][mk + 4];              /* band of bin k >= 5 is k + 4 (lanes k < 5 idle in the bin phase) */
+        gm[d] = 0.5f * GS * s_gain[d][132 - mk];            /* band of bin 128 - k */
+        sc[d] = uni ? s_gain[d][0] : 1.0f;                  /* frame scale of the overlap-add */
     }
+    const int hb = (lane & 3) + 1;                          /* hybrid items (wave 0): lane = (lagged hop u, bin b = 1..4) */
 
     /* ---- prologue: hops -6 .. -1 (ring positions 0 .. 5): bins 1..4 for the hybrid FIR; hops -3 .. -1 are the first
      *      three lagged slots of sub-chunk 0 ---- */
@@ -149,13 +162,14 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
         float* slot = s_ring + ff * SLOT;
         fft128_slot<false>(slot, fj, twJ, 0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (fj >= 1 && fj <= 4) s_low[(ff - 6 + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, Wlow);
+        if (fj >= 1 && fj <= 4) s_low[(ff - 6 + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, s_twl[fj]);
     }
     lds_barrier();      /* the first fold below wraps into ring positions 0 and 1 (hops 14, 15): the warm-up FFTs must be done with them */
 
-    float* zBase[D];
+    float* zBase[D];                                         /* uniform: the stores address  scalar base + 4 * tid */
 #pragma unroll
-    for (int d = 0; d < D; d++) zBase[d] = e.z + (long long)d * e.z_d + (long long)inst * e.z_inst + (long long)ch * e.z_ch + tid;
+    for (int d = 0; d < D; d++) zBase[d] = e.z + (long long)d * e.z_d + (long long)inst * e.z_inst + (long long)ch * e.z_ch;
+    int pN = 6;                                              /* ring position of hop s0 = (s0 + 6) % ERING */
 
     for (int s0 = 0; s0 < H; s0 += SUB) {
         const int n = min(SUB, H - s0);
@@ -166,7 +180,8 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
                 float fe = 0.0f, fo = 0.0f;
 #pragma unroll
                 for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
-                float* slot = s_ring + ((s0 + t + 6) % ERING) * SLOT;
+                const int pos = pN + t >= ERING ? pN + t - ERING : pN + t;
+                float* slot = s_ring + pos * SLOT;
                 slot[fn] = fe; slot[128 + fn] = fo;
             }
         }
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
 #pragma unroll
             for (int row = 0; row < SAF_ANA_HIST; row++) dst[row * SAF_HOP] = xin[SUB + 9 - SAF_ANA_HIST + row];
         }
-        /* slide the window, prefetch the next sub-chunk (consumed before the output stores of phase 6: vmcnt is in order) */
+        /* slide the window, prefetch the next sub-chunk (consumed before the output stores of phase 5: vmcnt is in order) */
 #pragma unroll
         for (int i = 0; i < 9; i++) xin[i] = xin[i + SUB];
         float xl[SUB];
@@ -188,95 +203,105 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
                 if (s0 + SUB + i + 1 < H) advance();
             }
         }
-        lds_barrier();                                       /* B1 */
+        const int pL = pN >= 3 ? pN - 3 : pN - 3 + ERING;      /* ring position of the first lagged hop s0 - 3 */
+        auto lag_slot = [&](int u) { const int pos = pL + u >= ERING ? pL + u - ERING : pL + u; return s_ring + pos * SLOT; };
         if (!uni) {
+            lds_barrier();                                   /* B1 */
             /* 2. 256-point real FFT as a 128-point complex FFT, in place; bins 1..4 of the new hop -> s_low */
             if (ff < n) {
-                float* slot = s_ring + ((s0 + ff + 6) % ERING) * SLOT;
+                float* slot = s_ring + (pN + ff >= ERING ? pN + ff - ERING : pN + ff) * SLOT;
                 fft128_slot<false>(slot, fj, twJ, 0);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (fj >= 1 && fj <= 4) s_low[(s0 + ff + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, Wlow);
+                if (fj >= 1 && fj <= 4) s_low[(s0 + ff + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, s_twl[fj]);
             }
             lds_barrier();                                   /* B2 */
-            /* 3. lagged hop hl = s0 - 3 + u.  Wave 0: hybrid bins (afSTFT_internal.c:595-619): band 2b-1 / 2b =
-             *    0.5 S_{hl}[b] -/+ (or +/-) g_b, g_b = i (C1 (S_{hl+3} - S_{hl-3}) + C2 (S_{hl+1} - S_{hl-1})), then the gains of
-             *    the two half-bands and their sum (afHybridInverse, :625-653).  Wave 1: DC and Nyquist, packed in place. */
-            if (wv == 0) {
-                const int u = lane >> 2, b = (lane & 3) + 1;
+            /* 3. bins k and 128-k of the lagged slots (lagged hop hl = s0 - 3 + u): real-FFT split (kiss_fftr.c:86-123), gains,
+             *    half-complex packing (kiss_fftr.c:125-161), in place.  2 Z'[k] = E + i O, 2 Z'[128-k] = conj(E - i O) with
+             *    E = B[k] + conj B[128-k], O = (B[k] - conj B[128-k]) e^{+2 pi i k / 256}. */
+            auto bin_pair = [&](float* slot, int u, int k, float2 W, const float (&ga)[D], const float (&gb)[D], bool hybrid, const float2 (&Bh)[D]) {
+                const float2 Zk = *reinterpret_cast<const float2*>(slot + 2 * k);
+                const float2 Zm = *reinterpret_cast<const float2*>(slot + 2 * (128 - k));
+                const float2 ee = make_float2(Zk.x + Zm.x, Zk.y - Zm.y);
+                const float2 dd = make_float2(Zk.x - Zm.x, Zk.y + Zm.y);
+                const float2 tt = cmul(W, dd);
+                const float2 Xk = make_float2(ee.x + tt.y, ee.y - tt.x);          /* 2 X[k] */
+                const float2 Xm = make_float2(ee.x - tt.y, -ee.y - tt.x);         /* 2 X[128-k] */
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    const float2 Bk = hybrid ? Bh[d] : make_float2(ga[d] * Xk.x, ga[d] * Xk.y);
+                    const float2 Bm = make_float2(gb[d] * Xm.x, gb[d] * Xm.y);
+                    const float2 E = make_float2(Bk.x + Bm.x, Bk.y - Bm.y);
+                    const float2 Dd = make_float2(Bk.x - Bm.x, Bk.y + Bm.y);
+                    const float2 O = make_float2(Dd.x * W.x + Dd.y * W.y, Dd.y * W.x - Dd.x * W.y);      /* Dd * conj(W) */
+                    float* o = d == 0 ? slot : s_out1 + u * SLOT;
+                    *reinterpret_cast<float2*>(o + 2 * k) = make_float2(E.x - O.y, E.y + O.x);
+                    if (k != 64) *reinterpret_cast<float2*>(o + 2 * (128 - k)) = make_float2(E.x + O.y, O.x - E.y);
+                }
+            };
+            /* a wave owns the lagged slots 8 wv .. 8 wv + 7 through phases 3 and 4 */
+            if (lane < 32) {
+                /* hybrid bins (afSTFT_internal.c:595-619): band 2b-1 / 2b = 0.5 S_{hl}[b] -/+ (or +/-) g_b,
+                 * g_b = i (C1 (S_{hl+3} - S_{hl-3}) + C2 (S_{hl+1} - S_{hl-1})); then the gains of the two half-bands and their sum
+                 * (afHybridInverse, :625-653) */
+                const int u = 8 * wv + (lane >> 2);
                 if (u < n) {
                     const int hl = s0 - 3 + u + 64;
-                    const float2 Dk = s_low[hl & (LOWR - 1)][b - 1];
-                    const float2 S0 = s_low[(hl + 3) & (LOWR - 1)][b - 1], S2 = s_low[(hl + 1) & (LOWR - 1)][b - 1];
-                    const float2 S4 = s_low[(hl - 1) & (LOWR - 1)][b - 1], S6 = s_low[(hl - 3) & (LOWR - 1)][b - 1];
+                    const float2 Dk = s_low[hl & (LOWR - 1)][hb - 1];
+                    const float2 S0 = s_low[(hl + 3) & (LOWR - 1)][hb - 1], S2 = s_low[(hl + 1) & (LOWR - 1)][hb - 1];
+                    const float2 S4 = s_low[(hl - 1) & (LOWR - 1)][hb - 1], S6 = s_low[(hl - 3) & (LOWR - 1)][hb - 1];
                     float gre, gim;
                     gre = -COEFF1 * S0.y;          gim = COEFF1 * S0.x;
                     gre -= COEFF2 * S2.y;          gim += COEFF2 * S2.x;
                     gre += COEFF2 * S4.y;          gim -= COEFF2 * S4.x;
                     gre += COEFF1 * S6.y;          gim -= COEFF1 * S6.x;
                     const float dr = Dk.x * 0.5f, di = Dk.y * 0.5f;
-                    const float sgn = (b & 1) ? -1.0f : 1.0f;
+                    const float sgn = (hb & 1) ? -1.0f : 1.0f;
                     const float2 lo = make_float2(dr + sgn * gre, di + sgn * gim), hi = make_float2(dr - sgn * gre, di - sgn * gim);
+                    float2 Bh[D]; float ghm[D];
 #pragma unroll
                     for (int d = 0; d < D; d++) {
-                        const float g1 = s_gain[d][2 * b - 1], g2 = s_gain[d][2 * b];
-                        s_hyb[d][u][b - 1] = make_float2(g1 * lo.x + g2 * hi.x, g1 * lo.y + g2 * hi.y);
+                        const float gh1 = GS * s_gain[d][2 * hb - 1], gh2 = GS * s_gain[d][2 * hb];
+                        ghm[d] = 0.5f * GS * s_gain[d][132 - hb];
+                        Bh[d] = make_float2(gh1 * lo.x + gh2 * hi.x, gh1 * lo.y + gh2 * hi.y);
                     }
+                    bin_pair(lag_slot(u), u, hb, s_twl[hb], ghm, ghm, true, Bh);
                 }
-            } else if (lane < n) {
-                const int u = lane;
-                float* slot = s_ring + ((s0 + 3 + u) % ERING) * SLOT;
-                const float2 Z0 = *reinterpret_cast<const float2*>(slot);
-                const float X0 = Z0.x + Z0.y, X128 = Z0.x - Z0.y;
-#pragma unroll
-                for (int d = 0; d < D; d++) {
-                    const float B0 = s_gain[d][0] * X0, B128 = s_gain[d][132] * X128;
-                    float* o = d == 0 ? slot : s_out1 + u * SLOT;
-                    *reinterpret_cast<float2*>(o) = make_float2(B0 + B128, B0 - B128);
-                }
-            }
-            lds_barrier();                                   /* B3 */
-            /* 4. bins k and 128-k of the lagged slots: real-FFT split (kiss_fftr.c:86-123), gains, half-complex packing
-             *    (kiss_fftr.c:125-161), in place.  2 Z'[k] = E + i O, 2 Z'[128-k] = conj(E - i O) with
-             *    E = B[k] + conj B[128-k], O = (B[k] - conj B[128-k]) e^{+2 pi i k / 256}. */
-#pragma unroll 2
-            for (int i = 0; i < SUB / 2; i++) {
-                const int u = wv + 2 * i;
+            } else if (lane < 40) {
+                /* DC and Nyquist: X[0] = Re Z[0] + Im Z[0], X[128] = Re Z[0] - Im Z[0]; packed back as (B0 + B128, B0 - B128) */
+                const int u = 8 * wv + lane - 32;
                 if (u < n) {
-                    float* slot = s_ring + ((s0 + 3 + u) % ERING) * SLOT;
-                    const float2 Zk = *reinterpret_cast<const float2*>(slot + 2 * mk);
-                    const float2 Zm = *reinterpret_cast<const float2*>(slot + 2 * (128 - mk));
-                    const float2 ee = make_float2(Zk.x + Zm.x, Zk.y - Zm.y);
-                    const float2 dd = make_float2(Zk.x - Zm.x, Zk.y + Zm.y);
-                    const float2 tt = cmul(Wk, dd);
-                    const float2 Xk = make_float2(ee.x + tt.y, ee.y - tt.x);          /* 2 X[k] */
-                    const float2 Xm = make_float2(ee.x - tt.y, -ee.y - tt.x);         /* 2 X[128-k] */
+                    float* slot = lag_slot(u);
+                    const float2 Z0 = *reinterpret_cast<const float2*>(slot);
+                    const float X0 = Z0.x + Z0.y, X128 = Z0.x - Z0.y;
 #pragma unroll
                     for (int d = 0; d < D; d++) {
-                        float2 Bk = make_float2(gk[d] * Xk.x, gk[d] * Xk.y);
-                        if (mk < 5) Bk = s_hyb[d][u][mk - 1];
-                        const float2 Bm = make_float2(gm[d] * Xm.x, gm[d] * Xm.y);
-                        const float2 E = make_float2(Bk.x + Bm.x, Bk.y - Bm.y);
-                        const float2 Dd = make_float2(Bk.x - Bm.x, Bk.y + Bm.y);
-                        const float2 O = make_float2(Dd.x * Wk.x + Dd.y * Wk.y, Dd.y * Wk.x - Dd.x * Wk.y);      /* Dd * conj(W) */
+                        const float B0 = GS * s_gain[d][0] * X0, B128 = GS * s_gain[d][132] * X128;
                         float* o = d == 0 ? slot : s_out1 + u * SLOT;
-                        *reinterpret_cast<float2*>(o + 2 * mk) = make_float2(E.x - O.y, E.y + O.x);
-                        if (mk != 64) *reinterpret_cast<float2*>(o + 2 * (128 - mk)) = make_float2(E.x + O.y, O.x - E.y);
+                        *reinterpret_cast<float2*>(o) = make_float2(B0 + B128, B0 - B128);
                     }
                 }
             }
-            lds_barrier();                                   /* B4 */
-            /* 5. inverse FFT in place: frame samples 2m, 2m+1 = Re, Im z[m] (x 1/256 in the overlap-add) */
+            if (mk >= 5) {
+                const float2 none[D] = {};
+#pragma unroll 2
+                for (int i = 0; i < SUB / 2; i++) {
+                    const int u = 8 * wv + i;
+                    if (u < n) bin_pair(lag_slot(u), u, mk, Wk, gk, gm, false, none);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            /* 4. inverse FFT of the wave's own 8 slots, in place: frame samples 2m, 2m+1 = Re, Im z[m] */
             if (ff < n) {
-                fft128_slot<true>(s_ring + ((s0 + 3 + ff) % ERING) * SLOT, fj, twJ, 0);
+                fft128_slot<true>(lag_slot(ff), fj, twJ, 0);
                 if (D > 1) fft128_slot<true>(s_out1 + ff * SLOT, fj, twJ, 0);
             }
-            lds_barrier();                                   /* B5 */
+            lds_barrier();                                   /* B3 */
         }
         if (more) {
 #pragma unroll
             for (int i = 0; i < SUB; i++) xin[9 + i] = xl[i] * scale;
         }
-        /* 6. 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0 + t is
+        /* 5. 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0 + t is
          *    sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n] */
 #pragma unroll
         for (int half = 0; half < SUB / EQ_OLA; half++) {
@@ -288,12 +313,12 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
                     for (int u = 0; u < EQ_OLA; u++) {
                         if (u < nh) {
                             const int uu = half * EQ_OLA + u;
-                            const float* slot = (d == 0 || uni) ? s_ring + ((s0 + 3 + uu) % ERING) * SLOT : s_out1 + uu * SLOT;
+                            const float* slot = (d == 0 || uni) ? lag_slot(uu) : s_out1 + uu * SLOT;
                             gl[d][9 + u] = slot[tid] * sc[d]; gr[d][9 + u] = slot[128 + tid] * sc[d];
                             float acc = 0.0f;
 #pragma unroll
                             for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
-                            zBase[d][(long long)(s0 + uu) * SAF_HOP] = acc;
+                            (zBase[d] + (long long)(s0 + uu) * SAF_HOP)[tid] = acc;
                         }
                     }
                     if (nh == EQ_OLA) {
@@ -311,7 +336,8 @@ __global__ __launch_bounds__(128, 2) void afstft_eq_kernel(EqArgs g)
                 }
             }
         }
-        lds_barrier();                                       /* B6: the next fold overwrites the slots just consumed */
+        pN = pN + SUB >= ERING ? pN + SUB - ERING : pN + SUB;
+        /* (no barrier: the next fold writes, and this overlap-add read, only the thread's own sample position of every slot) */
     }
 
     if ((H % SUB) != 0 && e.hist_wr) {                      /* partial last sub-chunk: the last 15 hops of [old history | input] */

@@ -6,6 +6,6 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile --no-band-independent > $R/gpurun_out/pmc_${TAG}_$i.json 2> $R/gpurun_out/pmc_${TAG}_$i.err || { tail -5 $R/gpurun_out/pmc_${TAG}_$i.err; exit 1; }
+  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_${TAG}_$i -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile --no-extra-paths ${BENCH_EXTRA:-} > $R/gpurun_out/pmc_${TAG}_$i.json 2> $R/gpurun_out/pmc_${TAG}_$i.err || { tail -5 $R/gpurun_out/pmc_${TAG}_$i.err; exit 1; }
 done
 python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_${TAG}_* 

@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0].replace("saf::", "")
-            if "afstft" in k or "gemm" in k or "pconv" in k or "binaural" in k or "cov" in k:
+            if "afstft" in k or "eq_kernel" in k or "gemm" in k or "pconv" in k or "binaural" in k or "cov" in k:
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     print(k)
