@@ -5,26 +5,31 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): order-7 ambi_dec, 64 SH in ->
-64 loudspeakers out (SphCovering-64, SAD, maxrE, energy-preserving), 512-sample
-blocks, synthetic uniform noise resident in HBM.  One *step* = one batched pass
-of the hot path over `instances` independent decoder instances x
-`frames_per_call` consecutive blocks (= instances*frames_per_call frames).
-Instances are independent, so N GPUs run N times the instances (weak scaling,
-no data-path collective); ranks only meet in the barriers and the max-reduce
-of the elapsed time.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run, one process
+per GPU, RCCL) BEFORE this process touches the GPU, relays rank 0's line and exits with the launcher's code.  Under a
+launcher (WORLD_SIZE set) a mismatch between WORLD_SIZE and --gpus is an error.
 
-Emits ONE JSON line with the contract fields plus
-  roofline     — for the kernel with the largest share of the step, from HIP
-                 events recorded on the launch stream around every kernel of
-                 the timed region (saf_hip_profile_*);
-  cpu_baseline — the CPU oracle (a port of the reference path, scalar, 1 core)
-                 timed on this host on a bounded sample of the same workload.
+Workload (BASELINE.json configs[1]): order-7 ambi_dec, 64 SH in -> 64 loudspeakers out (SphCovering-64, SAD,
+maxrE, energy-preserving), 512-sample blocks, synthetic uniform noise resident in HBM.  One *step* = one batched pass of
+the hot path over `instances` independent decoder instances x `frames_per_call` consecutive blocks.  Instances are
+independent, so N GPUs run N times the instances (weak scaling, no data-path collective); ranks only meet in the
+barriers and the max-reduce of the elapsed time.
+
+`value` is measured on the GENERAL form of the library's block path (saf_hip_ambi_dec_setTimeDomainPath(2)): every SH
+channel runs afSTFT analysis -> per-band gains -> afSTFT synthesis in one kernel (spectra stay on chip), then one
+time-domain MFMA GEMM applies the dense decoder.  It holds for any per-band order / max-rE / normalisation assignment.
+Extra keys (same sizes): `default_dispatch` (what the library does by default on THIS workload: its weights are the same
+in every band, so the transforms are skipped), `per_band_orders_workload` (every band its own order: default dispatch =
+the general form), `two_decoder_workload` (SAD below / EPAD above the transition: two dense matrices),
+`transform_path` (round 1's three-kernel path, spectra through HBM), `other_configs` (BASELINE configs[2..4], short
+regions), `cpu_baseline` (1 core) and `cpu_baseline_allcores` (one oracle instance per core).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,35 +39,46 @@ sys.path.insert(0, str(ROOT))
 
 FRAME = 512
 NCH = 64
-ALG_BYTES_PER_FRAME = {            # DESIGN.md §"Roofline accounting": the equaliser path (one dense decoder matrix)
-    "afstft_eq": 2 * NCH * FRAME * 4,                             # samples in + equalised SH signals out
+ALG_BYTES_PER_FRAME = {            # algorithmic bytes of each kernel per 512-sample frame of 64 channels
+    "afstft_eq": 2 * NCH * FRAME * 4,                             # samples in + equalised SH signals out (one dense decoder)
     "band_gemm": 2 * NCH * FRAME * 4,                             # equalised SH signals in + loudspeaker samples out
+    "afstft_analysis": NCH * FRAME * 4 + 133 * NCH * 4 * 8,      # transform path: samples in + spectra out
+    "afstft_synthesis": 133 * NCH * 4 * 8 + NCH * FRAME * 4,     # transform path: spectra in + samples out
 }
 PATH_BYTES_PER_FRAME = 2 * NCH * FRAME * 4                        # 262 144 B / frame
-GEMM_FLOP_PER_FRAME = 2 * 64 * 64 * FRAME                         # the dense decode in the time domain: 4.19 MFLOP / frame
-HBM_PEAK_GBS = 8000.0                                             # MI355X_MICROARCH.md: 8 TB/s spec
+GEMM_FLOP_PER_FRAME = 2 * 64 * 64 * FRAME                         # dense decode in the time domain: 4.19 MFLOP / frame
+HBM_PEAK_GBS = 8000.0                                             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3                                      # dense fp32-input MFMA peak
 
 
-def make_decoder(api_mod, cls):
+def make_decoder(cls, m0=1, m1=1):
     d = cls(FRAME)
     d.setNormType(1)                 # NORM_N3D
     d.setChOrder(1)                  # CH_ACN
     d.setMasterDecOrder(7)
     d.setOutputConfigPreset(29)      # LOUDSPEAKER_ARRAY_PRESET_SPH_COV_64
-    d.setDecMethod(0, 1)             # SAD below the transition
-    d.setDecMethod(1, 1)             # SAD above
+    d.setDecMethod(0, m0)            # 1 = SAD below the transition
+    d.setDecMethod(1, m1)            # above
     d.initCodec()
     d.init(48000)
     d.setDecOrderAllBands(7)
     return d
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """Oracle (port of the reference CPU path) on 1 core, same configuration, seeded noise."""
+def band_orders(seed=9):
+    """an arbitrary order per band, every order 1..7 present (what setDecOrder / the microphone presets produce)"""
+    import numpy as np
+    o = np.random.default_rng(seed).integers(1, 8, 133)
+    o[:7] = np.arange(1, 8)
+    return [int(v) for v in o]
+
+
+# ------------------------------------------------------------------------------------------------ CPU legs
+def cpu_run(seconds_budget):
+    """the CPU oracle (port of the reference path, scalar, one thread) on the headline configuration; (frames, seconds, stage times)"""
     import numpy as np
     from oracle import oracle as O
-    d = make_decoder(None, O.AmbiDec)
+    d = make_decoder(O.AmbiDec)
     rng = np.random.default_rng(0)
     x = (rng.random((8, NCH, FRAME), dtype=np.float32) * 2 - 1)
     for i in range(8):
@@ -74,12 +90,226 @@ def cpu_baseline(seconds_budget=12.0):
         n += 8
         if time.perf_counter() - t0 > seconds_budget:
             break
-    dt = time.perf_counter() - t0
-    f, g, b = d.stageTimes()
+    return n, time.perf_counter() - t0, d.stageTimes()
+
+
+def cpu_baseline(seconds_budget=8.0):
+    n, dt, (f, g, b) = cpu_run(seconds_budget)
     return {"value": round(n / dt, 1), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n} consecutive 512-sample blocks of one order-7 64->64 instance, {dt:.1f} s on 1 core "
                       f"(gcc -O3 -march=native, no BLAS; stage split afSTFT fwd/decode/afSTFT bwd = "
                       f"{1e3 * f / (n + 8):.3f}/{1e3 * g / (n + 8):.3f}/{1e3 * b / (n + 8):.3f} ms per block)"}
+
+
+def cpu_baseline_allcores(seconds_budget=8.0):
+    """N independent oracle instances, one process pinned to each core this process may run on"""
+    cores = sorted(os.sched_getaffinity(0))
+    procs = [subprocess.Popen([sys.executable, str(Path(__file__).resolve()), "--cpu-worker", str(seconds_budget), "--pin-core", str(c)],
+                              stdout=subprocess.PIPE, text=True) for c in cores]
+    frames, slowest = 0, 0.0
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            return None
+        n, dt = out.split()[-2:]
+        frames += int(n); slowest = max(slowest, float(dt))
+    return {"value": round(frames / slowest, 1), "unit": "frames/s", "cores": len(cores), "kind": "port",
+            "sample": f"{len(cores)} independent order-7 64->64 instances, one process pinned to each of the {len(cores)} cores of this process's "
+                      f"affinity mask (os.cpu_count() = {os.cpu_count()}), {frames} blocks in {slowest:.1f} s"}
+
+
+# ------------------------------------------------------------------------------------------------ multi-rank launch
+def spawn_ranks(n, argv):
+    """start n ranks of this script (one per GPU) with torch.distributed.run; this process has not touched the GPU"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + argv
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    import torch
+    from spatial_audio_framework_amd import parallel as P
+
+    world, rank, local_rank = P.env_world()
+    if args.dry_run:
+        # launch / rendezvous / reduction path without the GPU (tests/test_dist_cpu.py): gloo, no kernels
+        P.init(backend="gloo")
+        P.barrier()
+        elapsed = P.max_over_ranks(0.001 * (1 + rank))
+        if rank == 0:
+            print(json.dumps({"metric": "audio-frames/sec (512-sample, 128-ch, 7th-order ambi_dec)", "value": None, "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_elapsed": elapsed}), flush=True)
+        P.finalize()
+        return 0
+    if torch.cuda.device_count() <= 0:          # (counting devices does not initialise the GPU)
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+
+    # CPU legs first (rank 0 of a single-GPU run), before this process initialises the GPU: the all-cores leg starts child processes
+    cpu = cpu_all = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline()
+        cpu_all = cpu_baseline_allcores()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    P.init(backend="nccl", device=dev)          # RCCL; ranks only meet in the barriers and the MAX of the elapsed time
+
+    from spatial_audio_framework_amd import api
+    from spatial_audio_framework_amd._lib import load
+    L = load()
+    L.saf_hip_set_device(dev.index)
+    api.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    nI, nF = args.instances, args.frames_per_call
+    decs = [make_decoder(api.AmbiDec) for _ in range(nI)]
+    batch = api.AmbiDecBatch(decs, nF)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    # two alternating input sets so consecutive steps do not re-read identical data
+    xs = [torch.rand(nI, nF, NCH, FRAME, device=dev, generator=g) * 2 - 1 for _ in range(2)]
+    y = torch.zeros(nI, nF, NCH, FRAME, device=dev)
+    st = (nF * NCH * FRAME, NCH * FRAME, FRAME)
+
+    def timed_region(bt, mode, kernels, steps, warmup):
+        """`steps` timed passes on block path `mode` (saf_hip_ambi_dec_setTimeDomainPath) from a cleared filterbank state;
+        returns (max-over-ranks seconds, {kernel: (avg launch ms, launches)})"""
+        L.saf_hip_ambi_dec_setTimeDomainPath(mode)
+        bt.clear()
+        for i in range(warmup):
+            bt.process_ptr(xs[i & 1].data_ptr(), st, y.data_ptr(), st, nF)
+        torch.cuda.synchronize()
+        L.saf_hip_profile_reset()
+        L.saf_hip_profile_enable(0 if args.no_profile else 1)
+        P.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            bt.process_ptr(xs[i & 1].data_ptr(), st, y.data_ptr(), st, nF)
+        torch.cuda.synchronize()
+        P.barrier()
+        dt = time.perf_counter() - t0
+        L.saf_hip_profile_enable(0)
+        dt = P.max_over_ranks(dt, device=dev)
+        per = {}
+        for k in kernels:
+            tot = C.c_double()
+            n = L.saf_hip_profile_read(k.encode(), C.byref(tot))
+            if n:
+                per[k] = (tot.value / n, n)
+        assert bt.lastPath() == (0 if mode == 0 else 1)
+        return dt, per
+
+    def region_dict(dt, per, note):
+        return {"value": round(world * nI * nF * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
+                "kernels_ms": {k: round(v[0], 5) for k, v in per.items()}, "note": note}
+
+    EQK = ("afstft_eq", "band_gemm")
+    elapsed, general_kernels = timed_region(batch, 2, EQK, args.steps, args.warmup)
+    extra = {}
+    if not args.no_extra_paths:
+        w2 = max(2, args.warmup)
+        dt, per = timed_region(batch, 1, EQK, args.steps, w2)
+        extra["default_dispatch"] = region_dict(dt, per, "same workload, library default (mode 1): this workload's per-channel weights are the same in all 133 bands, so every "
+                                                         "channel skips the transforms (FFT / inverse FFT cancel, hybrid split + merge = its 3-hop delay); same outputs (parity tests)")
+        dt, per = timed_region(batch, 0, ("afstft_analysis", "band_gemm", "afstft_synthesis"), args.steps, w2)
+        extra["transform_path"] = region_dict(dt, per, "same workload on round 1's three-kernel path (mode 0): analysis -> per-band MFMA GEMM -> synthesis, spectra cross HBM four times")
+        orders = band_orders()
+        for d in decs:
+            for b, o in enumerate(orders):
+                d.setDecOrder(o, b)
+        dt, per = timed_region(batch, 1, EQK, args.steps, w2)
+        extra["per_band_orders_workload"] = region_dict(dt, per, "every band its own decoding order (1..7, max-rE on): library default = the general form, 14 different per-band matrices")
+        for d in decs:
+            d.setDecOrderAllBands(7)
+        del batch
+        decs2 = [make_decoder(api.AmbiDec, 1, 3) for _ in range(nI)]          # SAD below / EPAD above 800 Hz: two dense matrices
+        batch2 = api.AmbiDecBatch(decs2, nF)
+        dt, per = timed_region(batch2, 1, EQK, args.steps, w2)
+        extra["two_decoder_workload"] = region_dict(dt, per, "SAD below / EPAD above the 800 Hz transition (two different dense matrices): the equaliser kernel emits two signals per channel, "
+                                                             "the time-domain GEMM has two terms; algorithmic traffic 6 x 131 072 B per frame")
+        del batch2, decs2
+    L.saf_hip_ambi_dec_setTimeDomainPath(1)
+
+    frames_total = world * nI * nF * args.steps
+    value = frames_total / elapsed
+
+    other = None
+    if rank == 0 and not args.no_other_configs and not args.no_extra_paths:
+        del xs, y
+        torch.cuda.empty_cache()
+        sys.path.insert(0, str(ROOT / "tools"))
+        import bench_workloads as W
+        import numpy as np
+        i = np.arange(64) + 0.5
+        fib = np.stack([np.mod(np.degrees(np.pi * (1.0 + 5.0 ** 0.5) * i), 360.0) - 180.0, np.degrees(np.arcsin(1.0 - 2.0 * i / 64))], 1)
+        other = []
+        for fn in (lambda: W.binauraliser_batch(L, torch, api), lambda: W.matrixconv(L, torch, api), lambda: W.powermap(L, torch, api),
+                   lambda: W.enc_dec_chain(L, torch, api, fib)):
+            other.append(fn())
+
+    if rank == 0:
+        roof = None
+        if not args.no_profile and general_kernels:
+            per = general_kernels
+            dom = max(per, key=lambda k: per[k][0])
+            avg_ms, nl = per[dom]
+            frames_per_launch = nI * nF
+            traffic, traffic_source = None, None
+            tf = ROOT / "profiles" / "traffic_latest.json"
+            if tf.exists():          # PMC bytes per launch from an EARLIER run of the same launch size (tools/gpu_profile.sh), not measured in this run
+                try:
+                    tj = json.loads(tf.read_text())
+                    if tj.get("frames_per_launch") == frames_per_launch and dom in tj:
+                        traffic = tj[dom].get("hbm_bytes_per_launch")
+                        traffic_source = f"profiles/traffic_latest.json ({tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run')}); not measured in this run"
+                except Exception:
+                    traffic = None
+            ach = ALG_BYTES_PER_FRAME[dom] * frames_per_launch / (avg_ms * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source}
+            if dom == "afstft_eq":
+                roof["limiter"] = ("vector-instruction issue, not HBM: ~866 M VALU wave-instructions per launch "
+                                   "(profiles/r02_pmc_summary.txt); the kernel moves 262 144 B per frame, the floor of the path")
+            gm = per.get("band_gemm")
+            if gm:
+                tfl = GEMM_FLOP_PER_FRAME * frames_per_launch / (gm[0] * 1e-3) / 1e12
+                gb = ALG_BYTES_PER_FRAME["band_gemm"] * frames_per_launch / (gm[0] * 1e-3) / 1e9
+                roof["band_gemm"] = {"hbm": {"achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gb / HBM_PEAK_GBS, 4)},
+                                     "mfma": {"achieved": round(tfl, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tfl / MFMA_F32_PEAK_TFLOPS, 4)}}
+            roof["avg_launch_ms"] = round(avg_ms, 5)
+            roof["launches"] = nl
+            roof["kernels_ms"] = {k: round(v[0], 5) for k, v in per.items()}
+            roof["path_hbm_frac"] = round(PATH_BYTES_PER_FRAME * (value / world) / 1e9 / HBM_PEAK_GBS, 4)
+        line = {
+            "metric": "audio-frames/sec (512-sample, 128-ch, 7th-order ambi_dec)",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ambi_dec order 7: 64 SH in -> 64 loudspeakers out (SphCovering-64, SAD, maxrE, energy-preserving, N3D/ACN), "
+                                   "512-sample blocks, fs 48 kHz; batched device-resident entry point; general form of the block path "
+                                   "(per-channel filterbank equaliser + one time-domain GEMM, saf_hip_ambi_dec_setTimeDomainPath(2))",
+                       "instances_per_gpu": nI, "frames_per_step_per_instance": nF, "frames_per_step_per_gpu": nI * nF,
+                       "parallelism": f"independent instances sharded over {world} GPU(s), no collective on the data path"},
+            "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all,
+        }
+        line.update(extra)
+        if other is not None:
+            line["other_configs"] = other
+        if cpu:
+            line["speedup_vs_cpu_1core"] = round(value / cpu["value"], 1)
+        if cpu_all:
+            line["speedup_vs_cpu_allcores"] = round(value / cpu_all["value"], 1)
+        print(json.dumps(line), flush=True)
+    P.finalize()
+    return 0
 
 
 def main():
@@ -92,136 +322,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-extra-paths", action="store_true", help="only the headline timed region (used by the PMC passes)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short regions of the other BASELINE configs")
+    ap.add_argument("--dry-run", action="store_true", help="exercise launch / rendezvous / reduction with gloo, no GPU work (CPU tests)")
+    ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pin-core", type=int, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    import torch
-    from spatial_audio_framework_amd import parallel as P
+    if args.cpu_worker is not None:             # child of cpu_baseline_allcores: one oracle instance on one core, never touches the GPU
+        if args.pin_core is not None:
+            os.sched_setaffinity(0, {args.pin_core})
+        n, dt, _ = cpu_run(args.cpu_worker)
+        print(n, f"{dt:.4f}")
+        return 0
 
-    world, rank, local_rank = P.env_world()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
-    P.init(backend="nccl", device=dev)          # RCCL; ranks only meet in the barriers and the MAX of the elapsed time
-
-    from spatial_audio_framework_amd import api
-    from spatial_audio_framework_amd._lib import load
-    L = load()
-    L.saf_hip_set_device(dev.index)
-    api.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    nI, nF = args.instances, args.frames_per_call
-    decs = [make_decoder(api, api.AmbiDec) for _ in range(nI)]
-    batch = api.AmbiDecBatch(decs, nF)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    # two alternating input sets so consecutive steps do not re-read identical data
-    xs = [torch.rand(nI, nF, NCH, FRAME, device=dev, generator=g) * 2 - 1 for _ in range(2)]
-    y = torch.zeros(nI, nF, NCH, FRAME, device=dev)
-    st = (nF * NCH * FRAME, NCH * FRAME, FRAME)
-
-    def step(i):
-        batch.process_ptr(xs[i & 1].data_ptr(), st, y.data_ptr(), st, nF)
-
-    def timed_region(mode, kernels, steps, warmup):
-        """`steps` timed passes on block path `mode` (saf_hip_ambi_dec_setTimeDomainPath) from a cleared filterbank state;
-        returns (max-over-ranks seconds, {kernel: (avg launch ms, launches)})"""
-        L.saf_hip_ambi_dec_setTimeDomainPath(mode)
-        batch.clear()
-        for i in range(warmup):
-            step(i)
-        torch.cuda.synchronize()
-        L.saf_hip_profile_reset()
-        L.saf_hip_profile_enable(0 if args.no_profile else 1)
-        P.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step(i)
-        torch.cuda.synchronize()
-        P.barrier()
-        dt = time.perf_counter() - t0
-        L.saf_hip_profile_enable(0)
-        dt = P.max_over_ranks(dt, device=dev)
-        per = {}
-        for k in kernels:
-            tot = C.c_double()
-            n = L.saf_hip_profile_read(k.encode(), C.byref(tot))
-            if n:
-                per[k] = (tot.value / n, n)
-        return dt, per
-
-    # The headline number is measured on the GENERAL form of the equaliser path (mode 2): every SH channel runs
-    # analysis -> per-band gains -> synthesis on chip, then one time-domain MFMA GEMM applies the dense decoder.  That form
-    # holds for any per-band order / decoder weighting of ambi_dec.  This workload's weights happen to be the same in
-    # every band, so the library's default (mode 1) skips the transforms: reported separately as `default_dispatch`.
-    # The round-1 three-kernel transform path (mode 0) is reported as `transform_path`.
-    elapsed, general_kernels = timed_region(2, ("afstft_eq", "band_gemm"), args.steps, args.warmup)
-    extra = {}
-    if not args.no_extra_paths:
-        for key, mode, kern in (("default_dispatch", 1, ("afstft_eq", "band_gemm")), ("transform_path", 0, ("afstft_analysis", "band_gemm", "afstft_synthesis"))):
-            dt, per = timed_region(mode, kern, args.steps, max(2, args.warmup))
-            extra[key] = {"value": round(world * nI * nF * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
-                          "kernels_ms": {k: round(v[0], 5) for k, v in per.items()}}
-    L.saf_hip_ambi_dec_setTimeDomainPath(1)
-
-    frames_total = world * nI * nF * args.steps
-    value = frames_total / elapsed
-
-    if rank == 0:
-        roof = None
-        if not args.no_profile:
-            per = general_kernels
-            if per:
-                dom = max(per, key=lambda k: per[k][0])
-                avg_ms, nl = per[dom]
-                frames_per_launch = nI * nF
-                traffic = None
-                tf = ROOT / "profiles" / "traffic_latest.json"
-                if tf.exists():          # PMC bytes per launch, measured at a given launch size (tools/gpu_profile.sh)
-                    try:
-                        tj = json.loads(tf.read_text())
-                        if tj.get("frames_per_launch") == frames_per_launch:
-                            traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
-                    except Exception:
-                        traffic = None
-                ach = ALG_BYTES_PER_FRAME[dom] * frames_per_launch / (avg_ms * 1e-3) / 1e9
-                roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
-                if dom == "band_gemm":
-                    # the band GEMM streams its operands from HBM at 16 flop/B: both roofs are given, the binding one
-                    # (the larger fraction) is the `bound` (DESIGN.md 4.2)
-                    tf = GEMM_FLOP_PER_FRAME * frames_per_launch / (avg_ms * 1e-3) / 1e12
-                    mf = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
-                    if mf["frac"] > roof["frac"]:
-                        other = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
-                        roof.update(mf); roof["other_roof"] = other
-                    else:
-                        roof["other_roof"] = mf
-                roof["avg_launch_ms"] = round(avg_ms, 5)
-                roof["launches"] = nl
-                roof["kernels_ms"] = {k: round(v[0], 5) for k, v in per.items()}
-                roof["path_hbm_frac"] = round(PATH_BYTES_PER_FRAME * (value / world) / 1e9 / HBM_PEAK_GBS, 4)
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline()
-        line = {
-            "metric": "audio-frames/sec (512-sample, 128-ch, 7th-order ambi_dec)",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ambi_dec order 7: 64 SH in -> 64 loudspeakers out (SphCovering-64, SAD, maxrE, energy-preserving, N3D/ACN), "
-                                   "512-sample blocks, fs 48 kHz; batched device-resident entry point",
-                       "instances_per_gpu": nI, "frames_per_step_per_instance": nF, "frames_per_step_per_gpu": nI * nF,
-                       "parallelism": f"independent instances sharded over {world} GPU(s), no collective on the data path"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        line.update(extra)
-        if cpu:
-            line["speedup_vs_cpu_1core"] = round(value / cpu["value"], 1)
-        print(json.dumps(line), flush=True)
-    P.finalize()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return spawn_ranks(args.gpus, list(sys.argv[1:]))
+    if env_world is not None and int(env_world) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}; launch N ranks with --gpus N", file=sys.stderr)
+        return 2
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

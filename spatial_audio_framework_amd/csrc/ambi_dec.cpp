@@ -92,6 +92,7 @@ struct DecPipeline {
     DevBuf<int> zerosI;             /* [nInst][maxFrames] "band -> matrix 0" table of the time-domain GEMM */
     int zsynPar = 0, eqD = 1;
     std::vector<char> eqDirty, eqTwo;        /* per instance: tables stale; the two decoders are different matrices */
+    std::vector<unsigned long long> eqTwoEpoch;
     PinBuf<float> stageG, stageM; PinBuf<int> stageU;
     bool mode2Shadow = false;
     /* The overlap-add history lives in the loudspeaker domain on the transform path (AfState::syn) and in the SH domain on
@@ -154,7 +155,7 @@ struct DecPipeline {
         chScale.alloc((size_t)nInst * SAF_MAXCH);
         chMap.alloc((size_t)nInst * SAF_MAXCH);
         shadow.assign(nInst, Shadow());
-        eqDirty.assign(nInst, 1); eqTwo.assign(nInst, 0);
+        eqDirty.assign(nInst, 1); eqTwo.assign(nInst, 0); eqTwoEpoch.assign(nInst, ~0ull);
         stageA.ensure((size_t)NMAT * 64 * 64); stageI.ensure(SAF_NBANDS + SAF_MAXCH); stageS.ensure(SAF_MAXCH);
     }
 
@@ -200,20 +201,30 @@ struct DecPipeline {
             for (int d = 0; d < 2; d++) HIP_CHECK(hipMemsetAsync(zsyn[zsynPar].p + ((size_t)d * nInst + i) * nz, 0, nz * sizeof(float), stream()));
     }
 
-    /* tables of the equaliser path for the instances whose parameters changed (called after refresh()) */
-    void refresh_eq(int mode)
+    /* Do the two decoder slots of any instance hold different dense matrices?  Then the equaliser kernel has to emit two
+     * signals per channel (one per dense matrix: 1 forward, 2 inverse transforms, 42 KB of LDS per workgroup) and the GEMM has
+     * two terms: measured 3.0 M frames/s against 3.6 M on the transform path (profiles/r02_*), so the default mode sends such
+     * pipelines down the transform path; mode 2 still runs them on the equaliser path (parity-tested). */
+    bool two_dense_matrices()
     {
-        int D = 1;
+        bool two = false;
         for (int i = 0; i < nInst; i++) {
             AmbiDec* p = inst[i];
-            if (eqDirty[i]) {
+            if (eqTwoEpoch[i] != p->codecEpoch) {
                 const std::vector<float>& M0 = p->M_dec[0][p->masterOrder - 1];
                 const std::vector<float>& M1 = p->M_dec[1][p->masterOrder - 1];
                 eqTwo[i] = !(M0.size() == M1.size() && memcmp(M0.data(), M1.data(), M0.size() * sizeof(float)) == 0);
+                eqTwoEpoch[i] = p->codecEpoch;
             }
-            if (eqTwo[i]) D = 2;
+            two = two || eqTwo[i];
         }
-        ensure_eq_buffers(D);
+        return two;
+    }
+
+    /* tables of the equaliser path for the instances whose parameters changed (called after refresh()) */
+    void refresh_eq(int mode)
+    {
+        ensure_eq_buffers(two_dense_matrices() ? 2 : 1);
         const bool force = mode == 2;
         if (force != mode2Shadow) { std::fill(eqDirty.begin(), eqDirty.end(), 1); mode2Shadow = force; }
         for (int i = 0; i < nInst; i++) {
@@ -381,8 +392,9 @@ struct DecPipeline {
         const int H = nFrames * T;
         const int mode = g_ambi_dec_time_domain;
         /* the time-domain GEMM writes the caller's block with 16-byte stores */
-        const bool eq = !bin && mode != 0 && synDomain != DOM_LS &&
-                        ((out_inst | out_frame | out_ch) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0;
+        bool eq = !bin && mode != 0 && synDomain != DOM_LS &&
+                  ((out_inst | out_frame | out_ch) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0;
+        if (eq && mode == 1 && two_dense_matrices()) eq = false;      /* measured: see two_dense_matrices() */
         if (eq) {
             refresh_eq(mode);
             const long long zCh = (long long)Hmax * SAF_HOP, zInst = (long long)SAF_MAXCH * zCh, zD = (long long)nInst * zInst;

@@ -148,3 +148,26 @@ def test_shard_partition_properties():
             parts = [list(shard(n, world, r)) for r in range(world)]
             assert sum(parts, []) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def _bench(*argv, env=None):
+    import subprocess
+    e = dict(os.environ); e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher) starts two ranks itself before touching the GPU; --dry-run keeps the launch,
+    rendezvous (127.0.0.1), barrier and MAX-over-ranks path and skips the kernels, so this runs on the CPU with gloo."""
+    import json
+    r = _bench("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert abs(line["max_elapsed"] - 0.002) < 1e-9           # the slowest rank (rank 1) defines the job time
+
+
+def test_bench_rejects_world_size_mismatch():
+    r = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr

@@ -74,12 +74,14 @@ def test_equaliser_path_vs_oracle_and_transform_path(saf, orc, path, F, order, p
         path(mode)
         g = make(saf.AmbiDec, F, order, preset, m0, m1, norm, chord, orders, **kw)
         outs[mode] = run(g, x, nLS, F)
-        assert g.lastPath() == (0 if mode == 0 else 1)
+        # default mode: two different dense decoder matrices go down the transform path (measured faster); mode 2 forces the equaliser
+        assert g.lastPath() == (0 if mode == 0 or (mode == 1 and m0 != m1) else 1)
         assert relrms(outs[mode], yo) < TOL and relrms(outs[mode], yo) < 3e-6, mode
     assert relrms(outs[1], outs[0]) < 3e-6 and relrms(outs[2], outs[0]) < 3e-6
 
 
-def test_equaliser_path_parameter_changes_and_switch_to_transform(saf, orc, path):
+@pytest.mark.parametrize("m0,m1", [(1, 3), (3, 3)])
+def test_equaliser_path_parameter_changes_and_switch_to_transform(saf, orc, path, m0, m1):
     """Parameters changed between blocks act on the spectra of the following blocks exactly as in the reference (snapshot at
     block start, ambi_dec.c:479-488) — also when they flip channels between 'uniform' and 'needs the transforms'; then the
     pipeline is switched to the transform path mid-stream: the SH-domain overlap-add history is converted (exact)."""
@@ -87,7 +89,7 @@ def test_equaliser_path_parameter_changes_and_switch_to_transform(saf, orc, path
     x = frames(77, 36, 24 * F)
 
     def go(cls, sched):
-        d = make(cls, F, order, preset, 1, 3, 2)
+        d = make(cls, F, order, preset, m0, m1, 2)
         ys = []
         for b in range(24):
             if b == 4: d.setDecOrderAllBands(3)
@@ -104,7 +106,8 @@ def test_equaliser_path_parameter_changes_and_switch_to_transform(saf, orc, path
     for sched in ([1] * 24, [2] * 24, [1] * 9 + [0] * 15, [2] * 14 + [0] * 5 + [1] * 5):
         yg, d = go(saf.AmbiDec, sched)
         assert relrms(yg, yo) < 3e-6, sched
-        assert d.lastPath() == (0 if 0 in sched else 1)      # a pipeline that ran the transform path stays on it
+        # a pipeline that ran the transform path stays on it; two different dense matrices: default mode = transform path
+        assert d.lastPath() == (0 if (0 in sched or (m0 != m1 and 1 in sched)) else 1)
 
 
 def test_equaliser_path_missing_and_extra_channels(saf, orc, path):
@@ -113,7 +116,7 @@ def test_equaliser_path_missing_and_extra_channels(saf, orc, path):
     x = frames(31, 11, 20 * F)                       # 11 of 16 inputs
     for mode in (1, 2):
         path(mode)
-        g, o = make(saf.AmbiDec, F, order, 26, 1, 3, orders=band_orders(3, 5)), make(orc.AmbiDec, F, order, 26, 1, 3, orders=band_orders(3, 5))
+        g, o = make(saf.AmbiDec, F, order, 26, 3, 3, orders=band_orders(3, 5)), make(orc.AmbiDec, F, order, 26, 3, 3, orders=band_orders(3, 5))
         yg, yo = run(g, x, 20, F), run(o, x, 20, F)
         assert g.lastPath() == 1
         assert relrms(yg, yo) < 3e-6 and not yg[16:].any()
@@ -141,7 +144,7 @@ def test_equaliser_path_batch_split_invariance_and_strides(saf, orc, path):
                 bt.process_ptr(d_in[:, f0:].data_ptr(), st, d_out[:, f0:].data_ptr(), st, n)
                 f0 += n
             torch.cuda.synchronize()
-            assert bt.lastPath() == (0 if mode == 0 else 1)
+            assert bt.lastPath() == (1 if mode == 2 else 0)      # mixed decoders in the batch: default mode = transform path
             res[(mode, split)] = d_out.cpu().numpy()
         assert np.array_equal(res[(mode, (nF,))], res[(mode, (1, 2, 3))]), mode
     orcs = [make(orc.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs]
