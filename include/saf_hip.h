@@ -57,9 +57,14 @@ typedef enum {                      /* afSTFTlib.h:79-83 */
     AFSTFT_TIME_CH_BANDS
 } AFSTFT_FDDATA_FORMAT;
 
-/** afSTFTlib.h:107 / afSTFTlib.c:142. This build implements hopsize 128 (what every operator uses). */
+/** afSTFTlib.h:107 / afSTFTlib.c:142.  hopsize must be 128: the reference also accepts 64 and 256 (afSTFTlib.c:158-159),
+ *  but every operator of the path fixes HOP_SIZE at 128 (e.g. ambi_dec_internal.h:68, binauraliser_internal.h:63,
+ *  powermap_internal.h:67) and the kernels are specialised for it (1280-tap window, 256-point transform as 8 lanes x 16
+ *  points, 133 hybrid bands); another hop size aborts with a message instead of running an untested path. */
 SAF_API void afSTFT_create(void** const phSTFT, int nCHin, int nCHout, int hopsize, int lowDelayMode, int hybridmode, AFSTFT_FDDATA_FORMAT format);
 SAF_API void afSTFT_destroy(void** const phSTFT);                                                         /* afSTFTlib.h:120 */
+/** afSTFTlib.h:85 / afSTFTlib.c:78-119: one-shot analysis with a fresh filterbank; inTD [nSamplesTD][nCH], outTF [nBands][ceil(nSamplesTD/hop)][nCH]. */
+SAF_API void afAnalyse(float* inTD, int nSamplesTD, int nCH, int hopSize, int LDmode, int hybridmode, float_complex* outTF);
 SAF_API void afSTFT_forward(void* const hSTFT, float** dataTD, int framesize, float_complex*** dataFD);   /* afSTFTlib.h:130 */
 SAF_API void afSTFT_forward_knownDimensions(void* const hSTFT, float** dataTD, int framesize, int dataFD_nCH, int dataFD_nHops, float_complex*** dataFD); /* afSTFTlib.h:149 */
 SAF_API void afSTFT_forward_flat(void* const hSTFT, float* dataTD, int framesize, float_complex* dataFD); /* afSTFTlib.h:164 */
@@ -297,7 +302,9 @@ SAF_API int  ambi_enc_getProcessingDelay(void);                                 
  * encodes nFrames consecutive blocks of every instance (each output block is the encoding of the block
  * before it, exactly like consecutive ambi_enc_process calls; direction changes made through the set
  * functions take effect, cross-faded, on the first block of the next call).  Sample addressing as for
- * saf_hip_ambi_dec_batch_process; `nInputs` / `nOutputs` are the channel rows present in d_in / d_out. */
+ * saf_hip_ambi_dec_batch_process; `nInputs` / `nOutputs` are the channel rows present in d_in / d_out.
+ * d_in and d_out must not overlap (no in-place use: one launch reads block f while another workgroup writes block f);
+ * the same holds for saf_hip_rotator_process_dev and saf_hip_beamformer_process_dev.  Overlap aborts with a message. */
 SAF_API void* saf_hip_ambi_enc_batch_create(void* const* hAmbis, int nInst, int maxFramesPerCall);
 SAF_API void  saf_hip_ambi_enc_batch_destroy(void** const phBatch);
 SAF_API void  saf_hip_ambi_enc_batch_process(void* const hBatch,
@@ -436,12 +443,14 @@ SAF_API void saf_hip_binauraliser_getHRTFinterp(void* const hBin, float_complex*
  *  getter above applies to it (the reference's NF struct begins with the binauraliser members, binauraliser_nf_internal.h:61-137)
  *  and it is accepted by saf_hip_binauraliser_batch_create (all instances of a batch NF, or none).  Sources nearer than the
  *  far-field threshold (34 head radii) get the DVF shelf of their lateral angle and distance on each ear.
- *  binauraliserNF_processFD (binauraliser_nf.h:135) is declared by the reference but has no definition there; not provided. */
+ *  binauraliserNF_processFD (binauraliser_nf.h:135) is declared by the reference but has no definition there: its
+ *  binauraliserNF_process is the frequency-domain version (binauraliser_nf.c:224), so here both names are one function. */
 SAF_API void binauraliserNF_create(void** const phBin);                              /* binauraliser_nf.h:76 */
 SAF_API void binauraliserNF_destroy(void** const phBin);                             /* binauraliser_nf.h:83 */
 SAF_API void binauraliserNF_init(void* const hBin, int samplerate);                  /* binauraliser_nf.h:93 */
 SAF_API void binauraliserNF_initCodec(void* const hBin);                             /* binauraliser_nf.h:112 */
 SAF_API void binauraliserNF_process(void* const hBin, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* binauraliser_nf.h:124 */
+SAF_API void binauraliserNF_processFD(void* const hBin, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples); /* binauraliser_nf.h:135 */
 SAF_API void binauraliserNF_setSourceDist_m(void* const hBin, int index, float newDist_m);   /* binauraliser_nf.h:154 */
 SAF_API void binauraliserNF_setInputConfigPreset(void* const hBin, int newPresetID); /* binauraliser_nf.h:163 */
 SAF_API float binauraliserNF_getSourceDist_m(void* const hBin, int index);           /* binauraliser_nf.h:177 */

@@ -386,6 +386,44 @@ def beamWeights(kind, N):
     {1: lib().orc_beamWeightsCardioid2Spherical, 2: lib().orc_beamWeightsHypercardioid2Spherical, 3: lib().orc_beamWeightsMaxEV}[kind](N, fptr(b)); return b
 
 
+def convertHOAChannelConvention(sig, order, inConv, outConv):
+    """1 = ACN, 2 = FuMa (saf_hoa.c:40-76)"""
+    x = np.ascontiguousarray(sig, np.float32).copy()
+    lib().orc_convertHOAChannelConvention(fptr(x), order, x.shape[1], inConv, outConv); return x
+
+
+def convertHOANormConvention(sig, order, inConv, outConv):
+    """1 = N3D, 2 = SN3D, 3 = FuMa (saf_hoa.c:78-116)"""
+    x = np.ascontiguousarray(sig, np.float32).copy()
+    lib().orc_convertHOANormConvention(fptr(x), order, x.shape[1], inConv, outConv); return x
+
+
+def quaternion2rotationMatrix(q):
+    """q = (w, x, y, z) -> 3 x 3 (saf_utility_geometry.c:89)"""
+    q = np.ascontiguousarray(q, np.float32); R = np.zeros(9, np.float32)
+    lib().orc_quaternion2rotationMatrix(fptr(q), fptr(R)); return R.reshape(3, 3)
+
+
+def rotationMatrix2quaternion(R):
+    R = np.ascontiguousarray(R, np.float32).reshape(9); q = np.zeros(4, np.float32)
+    lib().orc_rotationMatrix2quaternion(fptr(R), fptr(q)); return q
+
+
+def euler2Quaternion(alpha, beta, gamma, degrees=False, convention=2):
+    """convention 2 = yaw-pitch-roll, 3 = roll-pitch-yaw (EULER_ROTATION_CONVENTIONS)"""
+    k = np.float32(np.pi / 180.0) if degrees else np.float32(1.0)
+    q = np.zeros(4, np.float32)
+    lib().orc_euler2Quaternion(C.c_float(float(np.float32(alpha) * k)), C.c_float(float(np.float32(beta) * k)), C.c_float(float(np.float32(gamma) * k)), convention, fptr(q))
+    return q
+
+
+def quaternion2euler(q, degrees=False, convention=2):
+    q = np.ascontiguousarray(q, np.float32); a, b, c = C.c_float(), C.c_float(), C.c_float()
+    lib().orc_quaternion2euler(fptr(q), convention, C.byref(a), C.byref(b), C.byref(c))
+    k = np.float32(180.0 / np.pi) if degrees else np.float32(1.0)
+    return np.array([a.value, b.value, c.value], np.float32) * k
+
+
 class Rotator:
     def __init__(self, frameSize=64):
         self.h = vp()

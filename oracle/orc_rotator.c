@@ -28,6 +28,15 @@ void orc_quaternion2rotationMatrix(const float q[4], float R[9])
     R[6] = 2.0f * (z * x - w * y); R[7] = 2.0f * (y * x + w * z); R[8] = 2.0f * (w * w + x * x) - 1.0f;
 }
 
+/* saf_utility_geometry.c:107-121: component magnitudes from the diagonal, signs from the antisymmetric part */
+void orc_rotationMatrix2quaternion(const float R[9], float q[4])
+{
+    q[0] = sqrtf(fmaxf(0.0f, 1.0f + R[0] + R[4] + R[8])) / 2.0f;
+    q[3] = copysignf(sqrtf(fmaxf(0.0f, 1.0f + R[0] - R[4] - R[8])) / 2.0f, R[7] - R[5]);
+    q[2] = copysignf(sqrtf(fmaxf(0.0f, 1.0f - R[0] + R[4] - R[8])) / 2.0f, R[2] - R[6]);
+    q[1] = copysignf(sqrtf(fmaxf(0.0f, 1.0f - R[0] - R[4] + R[8])) / 2.0f, R[3] - R[1]);
+}
+
 /* convention: 2 = yaw-pitch-roll, 3 = roll-pitch-yaw (EULER_ROTATION_CONVENTIONS); radians */
 void orc_euler2Quaternion(float alpha, float beta, float gamma, int convention, float q[4])
 {

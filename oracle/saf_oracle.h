@@ -242,6 +242,7 @@ void orc_beamformer_init(void* h, int fs);
 void orc_beamformer_process(void* h, const float* const* inputs, float* const* outputs, int nInputs, int nOutputs, int nSamples);
 /* ---- rotator example and quaternion helpers (orc_rotator.c) ---- */
 void orc_quaternion2rotationMatrix(const float q[4] /* w x y z */, float R[9]);
+void orc_rotationMatrix2quaternion(const float R[9], float q[4]);
 void orc_euler2Quaternion(float alpha, float beta, float gamma, int convention /* 2 ypr, 3 rpy */, float q[4]);
 void orc_quaternion2euler(const float q[4], int convention, float* alpha, float* beta, float* gamma);
 void orc_rotator_create(void** ph, int frameSize);

@@ -55,6 +55,7 @@ def load():
     sig("saf_hip_profile_read", ci, C.c_char_p, C.POINTER(C.c_double))
     # afSTFT
     sig("afSTFT_create", None, C.POINTER(vp), ci, ci, ci, ci, ci, ci)
+    sig("afAnalyse", None, fp, ci, ci, ci, ci, ci, vp)
     sig("afSTFT_destroy", None, C.POINTER(vp))
     sig("afSTFT_forward_flat", None, vp, fp, ci, vp)
     sig("afSTFT_backward_flat", None, vp, vp, ci, fp)
@@ -216,6 +217,7 @@ def load():
     sig("binauraliserNF_init", None, vp, ci)
     sig("binauraliserNF_initCodec", None, vp)
     sig("binauraliserNF_process", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
+    sig("binauraliserNF_processFD", None, vp, C.POINTER(fp), C.POINTER(fp), ci, ci, ci)
     sig("binauraliserNF_setSourceDist_m", None, vp, ci, cf)
     sig("binauraliserNF_setInputConfigPreset", None, vp, ci)
     sig("binauraliserNF_getSourceDist_m", cf, vp, ci)

@@ -113,6 +113,27 @@ class AfSTFT:
             self.L.afSTFT_destroy(C.byref(self.h))
 
 
+def afAnalyse(x_td, hopSize=128, LDmode=0, hybridmode=1):
+    """afAnalyse (afSTFTlib.h:85): x_td [nSamples][nCH] -> [nBands][ceil(nSamples / hop)][nCH], fresh filterbank"""
+    x = np.ascontiguousarray(x_td, np.float32); nS, nCH = x.shape
+    nB = hopSize + (5 if hybridmode else 1); nT = int(np.float32(nS) / np.float32(hopSize) + np.float32(0.9999))
+    out = np.zeros((nB, nT, nCH), np.complex64)
+    load().afAnalyse(_f(x), nS, nCH, hopSize, LDmode, hybridmode, out.ctypes.data_as(vp))
+    return out
+
+
+def convertHOAChannelConvention(sig, order, inConv, outConv):
+    """in place on a copy: sig [(order+1)^2][signalLength]; 1 = ACN, 2 = FuMa (saf_hoa.h:237)"""
+    x = np.ascontiguousarray(sig, np.float32).copy()
+    load().convertHOAChannelConvention(_f(x), order, x.shape[1], inConv, outConv); return x
+
+
+def convertHOANormConvention(sig, order, inConv, outConv):
+    """1 = N3D, 2 = SN3D, 3 = FuMa (saf_hoa.h:262)"""
+    x = np.ascontiguousarray(sig, np.float32).copy()
+    load().convertHOANormConvention(_f(x), order, x.shape[1], inConv, outConv); return x
+
+
 def afSTFT_getCentreFreqs_nullHandle(fs):
     f = np.zeros(133, np.float32)
     load().afSTFT_getCentreFreqs(None, C.c_float(fs), 133, _f(f))
@@ -590,6 +611,28 @@ def beamWeights(kind, N):
     {1: load().beamWeightsCardioid2Spherical, 2: load().beamWeightsHypercardioid2Spherical, 3: load().beamWeightsMaxEV}[kind](N, _f(b)); return b
 
 
+def quaternion2rotationMatrix(q):
+    """q = (w, x, y, z) -> 3 x 3 (saf_utility_geometry.h:60)"""
+    q = np.ascontiguousarray(q, np.float32); R = np.zeros((3, 3), np.float32)
+    load().quaternion2rotationMatrix(_f(q), _f(R)); return R
+
+
+def rotationMatrix2quaternion(R):
+    R = np.ascontiguousarray(R, np.float32); q = np.zeros(4, np.float32)
+    load().rotationMatrix2quaternion(_f(R), _f(q)); return q
+
+
+def euler2Quaternion(alpha, beta, gamma, degrees=False, convention=2):
+    q = np.zeros(4, np.float32)
+    load().euler2Quaternion(C.c_float(alpha), C.c_float(beta), C.c_float(gamma), int(degrees), convention, _f(q)); return q
+
+
+def quaternion2euler(q, degrees=False, convention=2):
+    q = np.ascontiguousarray(q, np.float32); a, b, c = C.c_float(), C.c_float(), C.c_float()
+    load().quaternion2euler(_f(q), int(degrees), convention, C.byref(a), C.byref(b), C.byref(c))
+    return np.array([a.value, b.value, c.value], np.float32)
+
+
 class Rotator:
     """rotator operator (examples/include/rotator.h)"""
 
@@ -719,6 +762,14 @@ class BinauraliserNF(Binauraliser):
         ns = x.shape[1] if nSamples is None else nSamples
         y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
         self.L.binauraliserNF_process(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
+        return y[:, :self.F]
+
+    def processFD(self, x, nOut=2, nSamples=None):
+        """binauraliserNF_processFD (binauraliser_nf.h:135)"""
+        x = np.ascontiguousarray(x, np.float32)
+        ns = x.shape[1] if nSamples is None else nSamples
+        y = np.full((nOut, max(ns, self.F)), np.nan, np.float32)
+        self.L.binauraliserNF_processFD(self.h, _rows(x), _rows(y), x.shape[0], nOut, ns)
         return y[:, :self.F]
 
     def process_dev(self, d_in, in_strides, nIn, d_out, out_strides, nFrames):

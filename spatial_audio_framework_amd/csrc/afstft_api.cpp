@@ -150,6 +150,30 @@ void afSTFT_create(void** const phSTFT, int nCHin, int nCHout, int hopsize, int 
     *phSTFT = h;
 }
 
+/* afAnalyse (afSTFTlib.c:78-119): one-shot analysis of nCH interleaved signals with a FRESH filterbank: the input is
+ * zero-padded to whole hops, outTF is [nBands][nTimeslots][nCH].  Same device path as afSTFT_forward. */
+void afAnalyse(float* inTD, int nSamplesTD, int nCH, int hopSize, int LDmode, int hybridmode, float_complex* outTF)
+{
+    if (nCH <= 0 || nSamplesTD <= 0) return;
+    void* hv = nullptr;
+    afSTFT_create(&hv, nCH, 1, hopSize, LDmode, hybridmode, AFSTFT_TIME_CH_BANDS);
+    AfSTFT* h = (AfSTFT*)hv;
+    const int nTimeSlots = (int)((float)nSamplesTD / (float)hopSize + 0.9999f);      /* the reference's "ceil" */
+    const int framesize = nTimeSlots * hopSize;
+    std::vector<float> td((size_t)nCH * framesize, 0.0f);
+    for (int ch = 0; ch < nCH; ch++)
+        for (int n = 0; n < nSamplesTD; n++) td[(size_t)ch * framesize + n] = inTD[(size_t)n * nCH + ch];
+    forward_host(h, framesize, [&](int ch) { return td.data() + (size_t)ch * framesize; });
+    const float2* r = h->h_fd.p;                                                     /* [band][ch][hop] */
+    for (int band = 0; band < h->nBands; band++)
+        for (int t = 0; t < nTimeSlots; t++)
+            for (int ch = 0; ch < nCH; ch++) {
+                const float2 v = r[((size_t)band * nCH + ch) * nTimeSlots + t];
+                outTF[((size_t)band * nTimeSlots + t) * nCH + ch] = float_complex(v.x, v.y);
+            }
+    afSTFT_destroy(&hv);
+}
+
 void afSTFT_destroy(void** const phSTFT)
 {
     if (!phSTFT || !*phSTFT) return;

@@ -692,6 +692,13 @@ void binauraliserNF_process(void* const hBin, const float* const* inputs, float*
     if (!p->nf) SAF_FATAL("binauraliserNF_process on a handle that was not made by binauraliserNF_create");
     process_host(p, inputs, outputs, nInputs, nOutputs, nSamples, true);
 }
+/* binauraliser_nf.h:135 declares this "alternate version that performs frequency-domain DVF filtering"; the reference's
+ * source never defines it — its binauraliserNF_process IS the frequency-domain version (binauraliser_nf.c:224) — so both
+ * names are the same function here. */
+void binauraliserNF_processFD(void* const hBin, const float* const* inputs, float** const outputs, int nInputs, int nOutputs, int nSamples)
+{
+    binauraliserNF_process(hBin, inputs, outputs, nInputs, nOutputs, nSamples);
+}
 void saf_hip_binauraliserNF_process_dev(void* const hBin, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs,
                                         float* d_out, long long out_frame_stride, long long out_ch_stride, int nFrames)
 {

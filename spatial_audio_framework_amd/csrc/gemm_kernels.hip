@@ -440,6 +440,20 @@ void launch_enc_gemm(const EncLaunch& e)
     if (e.nFrames <= 0 || e.nInst <= 0) return;
     if ((e.in_inst | e.in_frame | e.in_ch | e.out_inst | e.out_frame | e.out_ch | e.F) & 3) SAF_FATAL("ambi_enc: strides and block size must be multiples of 4 floats");
     if ((((uintptr_t)e.in) | ((uintptr_t)e.out)) & 15) SAF_FATAL("ambi_enc: sample buffers must be 16-byte aligned");
+    {
+        /* in-place use is not possible: within one launch the workgroup of block f writes output block f while the workgroup
+         * of block f + 1 (and the state-save block) reads input block f */
+        auto ext = [&](long long s_inst, long long s_frame, long long s_ch, int rows) {
+            auto a = [](long long v) { return v < 0 ? -v : v; };
+            return (long long)(e.nInst - 1) * a(s_inst) + (long long)(e.nFrames - 1) * a(s_frame) + (long long)(rows > 0 ? rows - 1 : 0) * a(s_ch) + e.F;
+        };
+        const int rowsIn = e.maxSteps > 0 && 2 * e.maxSteps < SAF_MAXCH ? 2 * e.maxSteps : SAF_MAXCH;       /* rows the kernels can touch */
+        const int rowsOut = e.nOut < SAF_MAXCH ? e.nOut : SAF_MAXCH;
+        const float* i0 = e.in; const float* i1 = e.in + ext(e.in_inst, e.in_frame, e.in_ch, rowsIn);
+        const float* o0 = e.out; const float* o1 = e.out + ext(e.out_inst, e.out_frame, e.out_ch, rowsOut);
+        if (i0 < o1 && o0 < i1)
+            SAF_FATAL("encode GEMM (ambi_enc / rotator / beamformer *_process_dev, batch_process): input and output buffers overlap; the device entry points do not work in place");
+    }
     EncArgs a;
     a.e = e;
     KernelTimer kt("sh_encode");

@@ -5,14 +5,18 @@
  */
 #include "saf_hip_common.h"
 #include "../../include/saf_hip.h"
+#include <mutex>
 
 namespace saf {
 
+/* Operators are called from several host threads (initCodec on a worker thread while process runs on the audio thread,
+ * SURVEY §8b "Threading"): the first call of each may arrive together, so device check and stream creation are serialised. */
+static std::mutex g_rt_mutex;
 static hipStream_t g_stream = nullptr;
 static bool g_own_stream = false;
 static bool g_checked = false;
 
-void ensure_device()
+static void ensure_device_locked()
 {
     if (g_checked) return;
     int n = 0;
@@ -23,23 +27,37 @@ void ensure_device()
     g_checked = true;
 }
 
+void ensure_device()
+{
+    std::lock_guard<std::mutex> lk(g_rt_mutex);
+    ensure_device_locked();
+}
+
 hipStream_t stream()
 {
+    /* fast path: the pointer is written once under the lock (and by set_stream, which callers do not race with launches) */
+    hipStream_t s = __atomic_load_n(&g_stream, __ATOMIC_ACQUIRE);
+    if (s) return s;
+    std::lock_guard<std::mutex> lk(g_rt_mutex);
     if (!g_stream) {
-        ensure_device();
-        HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        ensure_device_locked();
+        hipStream_t ns = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
         g_own_stream = true;
+        __atomic_store_n(&g_stream, ns, __ATOMIC_RELEASE);
     }
     return g_stream;
 }
 
 void set_stream(hipStream_t s)
 {
-    ensure_device();
+    std::lock_guard<std::mutex> lk(g_rt_mutex);
+    ensure_device_locked();
     if (g_stream && g_own_stream) { HIP_CHECK(hipStreamSynchronize(g_stream)); HIP_CHECK(hipStreamDestroy(g_stream)); }
-    g_stream = s;
     g_own_stream = false;
-    if (!g_stream) { HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking)); g_own_stream = true; }
+    hipStream_t ns = s;
+    if (!ns) { HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking)); g_own_stream = true; }
+    __atomic_store_n(&g_stream, ns, __ATOMIC_RELEASE);
 }
 
 /* ---- host-pointer entry points: zero-copy I/O ---- */
@@ -50,19 +68,23 @@ bool zero_copy_io() { return g_zero_copy != 0; }
 struct ProfRec { const char* name; hipEvent_t a, b; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
+static std::mutex g_prof_mutex;          /* launches may come from several host threads while profiling is on */
 
 KernelTimer::KernelTimer(const char* name) : slot(-1)
 {
     if (!g_prof) return;
     ProfRec r; r.name = name;
     HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b));
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
     HIP_CHECK(hipEventRecord(r.a, stream()));
     g_recs.push_back(r);
     slot = (int)g_recs.size() - 1;
 }
 KernelTimer::~KernelTimer()
 {
-    if (slot >= 0) HIP_CHECK(hipEventRecord(g_recs[slot].b, stream()));
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mutex);
+    if (slot < (int)g_recs.size()) HIP_CHECK(hipEventRecord(g_recs[slot].b, stream()));
 }
 
 }  // namespace saf
@@ -73,6 +95,7 @@ void saf_hip_profile_enable(int on) { saf::g_prof = on != 0; }
 void saf_hip_profile_reset(void)
 {
     HIP_CHECK(hipStreamSynchronize(saf::stream()));
+    std::lock_guard<std::mutex> lk(saf::g_prof_mutex);
     for (auto& r : saf::g_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     saf::g_recs.clear();
 }
@@ -80,6 +103,7 @@ void saf_hip_profile_reset(void)
 int saf_hip_profile_read(const char* name, double* total_ms)
 {
     HIP_CHECK(hipStreamSynchronize(saf::stream()));
+    std::lock_guard<std::mutex> lk(saf::g_prof_mutex);
     int n = 0; double t = 0.0;
     for (auto& r : saf::g_recs)
         if (!strcmp(r.name, name)) { float ms = 0.f; HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b)); t += ms; n++; }

@@ -1,0 +1,169 @@
+"""Entry points of the boundary that had no direct test: afAnalyse, binauraliserNF_processFD, the stand-alone
+convertHOA*Convention functions; plus thread-safety and handle life-cycle of the operators (SURVEY §8b "Threading",
+ambi_dec.c:196-205).  Needs an MI355X:  python -m pytest tests -m gpu"""
+import gc
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from util import frames, relrms, synth_hrirs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_afAnalyse_equals_fresh_forward_transform(saf, orc):
+    """afAnalyse (afSTFTlib.c:78-119) = afSTFT_forward of a FRESH filterbank on the zero-padded signals, output [band][slot][ch]"""
+    nS, nCH = 5 * 128 + 37, 3                       # not a whole number of hops: zero padded to 6 slots
+    x = frames(11, nCH, nS)
+    for hyb, ld in ((1, 0), (0, 0), (1, 1)):
+        A = saf.afAnalyse(x.T.copy(), 128, ld, hyb)
+        nB = 133 if hyb else 129
+        assert A.shape == (nB, 6, nCH)
+        xp = np.zeros((nCH, 6 * 128), np.float32); xp[:, :nS] = x
+        o = orc.AfSTFT(nCH, 1, 128, ld, hyb)
+        ref = o.forward(xp)                         # [band][ch][hop]
+        assert relrms(A, np.transpose(ref, (0, 2, 1))) < 1e-6
+        f = saf.AfSTFT(nCH, 1, 128, ld, hyb)
+        assert np.array_equal(A, np.transpose(f.forward(xp), (0, 2, 1)))          # the same device path
+
+
+def test_binauraliserNF_processFD_is_the_frequency_domain_process(saf):
+    """binauraliser_nf.h:135 declares it, binauraliser_nf.c never defines it (its binauraliserNF_process is the frequency-domain
+    version): both names are one function"""
+    h, d = synth_hrirs()
+
+    def mk():
+        b = saf.BinauraliserNF(128, 64); b.setHRIRs(h, d, 48000); b.init(48000); b.setNumSources(5); b.initCodec()
+        for i in range(5):
+            b.setSourceAzi_deg(i, 40.0 * i - 80.0); b.setSourceElev_deg(i, 10.0 * i - 20.0); b.setSourceDist_m(i, 0.2 + 0.4 * i)
+        return b
+    a, b = mk(), mk()
+    x = frames(3, 5, 20 * 128)
+    ya = np.concatenate([a.process(x[:, i * 128:(i + 1) * 128]) for i in range(20)], 1)
+    yb = np.concatenate([b.processFD(x[:, i * 128:(i + 1) * 128]) for i in range(20)], 1)
+    assert np.abs(ya).max() > 1e-3 and np.array_equal(ya, yb)
+
+
+@pytest.mark.parametrize("order", [1, 3, 7])
+def test_convertHOA_conventions_direct(saf, orc, order):
+    """convertHOAChannelConvention / convertHOANormConvention (saf_hoa.c:40-116) called directly: equal to the oracle bit for
+    bit, inverse pairs give the input back, FuMa only touches first order (higher channels are left alone there too)"""
+    nSH = (order + 1) ** 2
+    x = frames(40 + order, nSH, 64)
+    for a, b in ((1, 2), (2, 1), (1, 3), (3, 1), (2, 3), (3, 2)):
+        if 3 in (a, b) and order != 1:
+            continue
+        y = saf.convertHOANormConvention(x, order, a, b)
+        assert np.array_equal(y, orc.convertHOANormConvention(x, order, a, b)), (a, b)
+        assert np.abs(saf.convertHOANormConvention(y, order, b, a) - x).max() < 1e-6
+    sn = saf.convertHOANormConvention(x, order, 1, 2)                  # N3D -> SN3D divides order n by sqrt(2n+1)
+    for n in range(order + 1):
+        assert np.allclose(sn[n * n:(n + 1) ** 2], x[n * n:(n + 1) ** 2] / np.sqrt(np.float32(2 * n + 1)), rtol=1e-6)
+    if order == 1:
+        for a, b in ((1, 2), (2, 1)):
+            y = saf.convertHOAChannelConvention(x, order, a, b)
+            assert np.array_equal(y, orc.convertHOAChannelConvention(x, order, a, b))
+            assert np.array_equal(saf.convertHOAChannelConvention(y, order, b, a), x)
+        assert np.array_equal(saf.convertHOAChannelConvention(x, 1, 1, 2), x[[0, 3, 1, 2]])        # ACN WYZX -> FuMa WXYZ
+
+
+def test_initCodec_on_second_thread_while_processing(saf):
+    """the reference mutes the output while the codec initialises on another thread (ambi_dec.c:196-205, 491-492, 575-579):
+    nothing may crash, hang or produce non-finite samples, and afterwards the new configuration renders"""
+    F = 128
+    a = saf.AmbiDec(F)
+    a.setMasterDecOrder(3); a.setOutputConfigPreset(21); a.initCodec(); a.init(48000)
+    x = frames(1, 16, 200 * F)
+    state = {"stop": False, "blocks": 0, "bad": 0}
+
+    def audio():
+        i = 0
+        while not state["stop"]:
+            y = a.process(np.ascontiguousarray(x[:, (i % 200) * F:(i % 200 + 1) * F]), 24)
+            state["blocks"] += 1
+            if not np.isfinite(y).all():
+                state["bad"] += 1
+            i += 1
+
+    t = threading.Thread(target=audio)
+    t.start()
+    for k in range(8):
+        time.sleep(0.03)
+        a.setOutputConfigPreset(21 if k % 2 else 29)     # structural change -> codec not initialised
+        a.setDecMethod(0, 1 + k % 3)
+        a.initCodec()                                    # on this (second) thread
+    state["stop"] = True
+    t.join(timeout=60)
+    assert not t.is_alive() and state["bad"] == 0 and state["blocks"] > 20
+    n = a.getNumLoudspeakers()
+    y = np.concatenate([a.process(np.ascontiguousarray(x[:, i * F:(i + 1) * F]), n) for i in range(16)], 1)
+    assert np.isfinite(y).all() and np.abs(y[:, 13 * F:]).max() > 1e-3
+
+
+def test_two_threads_create_and_run_operators_concurrently(saf):
+    """first use of the library from two threads at once (stream creation and device check are serialised, runtime.cpp)"""
+    errs = []
+
+    def work(seed):
+        try:
+            e = saf.AmbiEnc(128); e.init(48000); e.setOutputOrder(3); e.setNumSources(4)
+            x = frames(seed, 4, 128)
+            for _ in range(30):
+                y = e.process(x, 16)
+            assert np.isfinite(y).all() and np.abs(y).max() > 0
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+    ts = [threading.Thread(target=work, args=(s,)) for s in (5, 6)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=120)
+    assert not errs and not any(t.is_alive() for t in ts)
+
+
+def test_operator_lifecycle_does_not_leak_device_memory(saf):
+    """create / run / destroy every operator of the path repeatedly: the free device memory must not shrink (every device and
+    pinned buffer is owned by its handle and released by X_destroy)"""
+    import torch
+    h, d = synth_hrirs()
+    x64 = frames(1, 64, 512)
+
+    def free_mib():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0] / 2 ** 20
+
+    def loop(make, run, n):
+        run(make()); gc.collect()
+        f0 = free_mib()
+        for _ in range(n):
+            run(make())
+        gc.collect()
+        return free_mib() - f0
+
+    def dec():
+        a = saf.AmbiDec(128); a.setMasterDecOrder(3); a.setOutputConfigPreset(21); a.initCodec(); a.init(48000); return a
+
+    def dec_orders():      # equaliser path with transforms
+        a = dec()
+        for b in range(133): a.setDecOrder(1 + b % 3, b)
+        return a
+
+    def enc():
+        e = saf.AmbiEnc(128); e.init(48000); e.setOutputOrder(3); e.setNumSources(8); return e
+
+    def bina():
+        b = saf.Binauraliser(128, 64); b.setHRIRs(h, d, 48000); b.init(48000); b.setNumSources(8); b.initCodec(); return b
+
+    def pm():
+        p = saf.Powermap(1024); p.setMasterOrder(3); p.init(48000.0); p.initCodec(); return p
+
+    H = (np.random.default_rng(0).normal(size=(2, 8, 600)) / 8).astype(np.float32)
+    deltas = {
+        "ambi_dec": loop(dec, lambda a: [a.process(x64[:16, :128], 24) for _ in range(3)], 15),
+        "ambi_dec_eq": loop(dec_orders, lambda a: [a.process(x64[:16, :128], 24) for _ in range(3)], 15),
+        "ambi_enc": loop(enc, lambda e: [e.process(x64[:8, :128], 16) for _ in range(3)], 15),
+        "binauraliser": loop(bina, lambda b: [b.process(x64[:8, :128]) for _ in range(3)], 6),
+        "matrixConv": loop(lambda: saf.MatrixConv(128, H, 1), lambda m: [m.apply(x64[:8, :128]) for _ in range(3)], 15),
+        "powermap": loop(pm, lambda p: [p.analysis(frames(3, 16, 1024)) for _ in range(2)], 6),
+    }
+    assert all(v > -8.0 for v in deltas.values()), deltas      # MiB; allocator granularity, not growth per cycle

@@ -501,7 +501,9 @@ def test_adaptive_map_generators_closed_forms(orc):
 
 
 def test_binaural_ambi_decoders_closed_forms(orc):
-    """getSHrotMtxReal / getBinauralAmbiDecoderMtx / applyDiffCovMatching / truncationEQ have no reference test.  Closed forms:
+    """getBinauralAmbiDecoderMtx / applyDiffCovMatching have no reference test; getSHrotMtxReal and truncationEQ do
+    (test__getSHrotMtxReal: a 25 x 25 MATLAB matrix, test__truncationEQ: gain bounds) and are pinned on them in
+    tests/test_reference_vectors_cpu.py / tests/test_gpu_reference_vectors.py.  Additional closed forms here:
     the rotation matrix is orthonormal and maps the SH of directions to the SH of the rotated directions; an order-limited
     HRTF set is decoded exactly by LS and LSDIFFEQ (gain 1); max-rE scales each order by its weight; after covariance
     matching the order-limited set has the diffuse-field covariance of the original (the Nyquist band is left alone);
