@@ -123,13 +123,13 @@ def afAnalyse(x_td, hopSize=128, LDmode=0, hybridmode=1):
 
 
 def convertHOAChannelConvention(sig, order, inConv, outConv):
-    """in place on a copy: sig [(order+1)^2][signalLength]; 1 = ACN, 2 = FuMa (saf_hoa.h:237)"""
+    """in place on a copy: sig [(order+1)^2][signalLength]; HOA_CH_ORDER: 0 = ACN, 1 = FuMa (saf_hoa.h:183-192, 237)"""
     x = np.ascontiguousarray(sig, np.float32).copy()
     load().convertHOAChannelConvention(_f(x), order, x.shape[1], inConv, outConv); return x
 
 
 def convertHOANormConvention(sig, order, inConv, outConv):
-    """1 = N3D, 2 = SN3D, 3 = FuMa (saf_hoa.h:262)"""
+    """HOA_NORM: 0 = N3D, 1 = SN3D, 2 = FuMa (saf_hoa.h:203-213, 262)"""
     x = np.ascontiguousarray(sig, np.float32).copy()
     load().convertHOANormConvention(_f(x), order, x.shape[1], inConv, outConv); return x
 

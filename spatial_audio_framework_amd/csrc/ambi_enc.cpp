@@ -134,7 +134,7 @@ struct EncPipeline {
         e.Afrag = Afrag.p; e.gains = d_gains; e.postScale = d_post; e.rowScale = d_rowScale; e.rowMap = d_rowMap;
         e.nSrc = d_nSrc; e.order = d_order; e.mix = anyRecalc ? d_mix : nullptr;
         e.F = F; e.nFrames = nFrames; e.nInst = n; e.nOut = nOut < SAF_MAXCH ? nOut : SAF_MAXCH;
-        for (int i = 0; i < n; i++) e.maxSteps = std::max(e.maxSteps, (shadowI[i] + 1) / 2);
+        for (int i = 0; i < n; i++) { e.maxSteps = std::max(e.maxSteps, (shadowI[i] + 1) / 2); e.rowsIn = std::max(e.rowsIn, shadowI[i]); }
         launch_enc_gemm(e);
         par ^= 1;
         if (anyRecalc)      /* prev_Y <- Y for the instances that mixed (ambi_enc.c:162) */

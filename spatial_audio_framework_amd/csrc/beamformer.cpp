@@ -173,7 +173,7 @@ static void bf_run(Beamformer* p, const float* in, long long in_frame, long long
     e.Afrag = p->Afrag.p + p->cur * 4096; e.AfragPrev = p->Afrag.p + (p->cur ^ 1) * 4096; e.postScale = p->fpar.p; e.gains = p->fpar.p + 1; e.rowScale = p->fpar.p + 65;
     e.nSrc = p->ipar.p; e.mix = mix ? p->ipar.p + 1 : nullptr; e.order = p->ipar.p + 2; e.rowMap = p->ipar.p + 3;
     e.F = F; e.nFrames = nFrames; e.nInst = 1; e.nOut = nOut < nBeams ? nOut : nBeams;
-    e.maxSteps = (nSrc + 1) / 2;
+    e.maxSteps = (nSrc + 1) / 2; e.rowsIn = nSrc;
     launch_enc_gemm(e);
     p->par ^= 1;
     if (mix) memcpy(p->prevW, p->W, sizeof(p->W));            /* prev_beamWeights <- beamWeights (beamformer.c:171): on the device the slots swap at the next change */

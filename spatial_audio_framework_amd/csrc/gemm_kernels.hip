@@ -447,7 +447,7 @@ void launch_enc_gemm(const EncLaunch& e)
             auto a = [](long long v) { return v < 0 ? -v : v; };
             return (long long)(e.nInst - 1) * a(s_inst) + (long long)(e.nFrames - 1) * a(s_frame) + (long long)(rows > 0 ? rows - 1 : 0) * a(s_ch) + e.F;
         };
-        const int rowsIn = e.maxSteps > 0 && 2 * e.maxSteps < SAF_MAXCH ? 2 * e.maxSteps : SAF_MAXCH;       /* rows the kernels can touch */
+        const int rowsIn = e.rowsIn > 0 && e.rowsIn < SAF_MAXCH ? e.rowsIn : SAF_MAXCH;       /* rows the kernels can touch (higher rows re-read the last one) */
         const int rowsOut = e.nOut < SAF_MAXCH ? e.nOut : SAF_MAXCH;
         const float* i0 = e.in; const float* i1 = e.in + ext(e.in_inst, e.in_frame, e.in_ch, rowsIn);
         const float* o0 = e.out; const float* o1 = e.out + ext(e.out_inst, e.out_frame, e.out_ch, rowsOut);

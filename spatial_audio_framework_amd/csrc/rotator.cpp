@@ -106,7 +106,7 @@ static void rot_run(Rotator* p, const float* in, long long in_frame, long long i
     e.Afrag = p->Afrag.p + p->cur * 4096; e.AfragPrev = p->Afrag.p + (p->cur ^ 1) * 4096; e.postScale = p->fpar.p; e.gains = p->fpar.p + 1; e.rowScale = p->fpar.p + 65;
     e.nSrc = p->ipar.p; e.mix = mix ? p->ipar.p + 1 : nullptr; e.order = p->ipar.p + 2; e.rowMap = p->ipar.p + 3;
     e.F = F; e.nFrames = nFrames; e.nInst = 1; e.nOut = nOut < SAF_MAXCH ? nOut : SAF_MAXCH;
-    e.maxSteps = (nSrc + 1) / 2;
+    e.maxSteps = (nSrc + 1) / 2; e.rowsIn = nSrc;
     launch_enc_gemm(e);
     p->par ^= 1;
     if (mix) memcpy(p->prev_M_rot, p->M_rot, sizeof(p->M_rot));     /* prev_M_rot <- M_rot (rotator.c:170): on the device the slots swap at the next change */

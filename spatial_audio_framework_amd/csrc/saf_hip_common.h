@@ -225,6 +225,7 @@ struct EncLaunch {
     const int* mix;                           /* [nInst] 1: frame 0 cross-fades Y with prev_Y; null: nobody mixes */
     int F, nFrames, nInst, nOut;
     int maxSteps;                             /* max over instances of ceil(nSrc / 2) (0: unknown) */
+    int rowsIn = 0;                           /* max over instances of the input rows read (0: unknown; used by the overlap check) */
 };
 void launch_enc_gemm(const EncLaunch& e);
 

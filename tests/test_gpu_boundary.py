@@ -52,21 +52,23 @@ def test_convertHOA_conventions_direct(saf, orc, order):
     bit, inverse pairs give the input back, FuMa only touches first order (higher channels are left alone there too)"""
     nSH = (order + 1) ** 2
     x = frames(40 + order, nSH, 64)
+    # the library takes the reference's enums (HOA_NORM_N3D / SN3D / FUMA = 0 / 1 / 2, HOA_CH_ORDER_ACN / FUMA = 0 / 1);
+    # the oracle's helper counts from 1 like the operators' NORM_TYPES / CH_ORDER
     for a, b in ((1, 2), (2, 1), (1, 3), (3, 1), (2, 3), (3, 2)):
         if 3 in (a, b) and order != 1:
             continue
-        y = saf.convertHOANormConvention(x, order, a, b)
+        y = saf.convertHOANormConvention(x, order, a - 1, b - 1)
         assert np.array_equal(y, orc.convertHOANormConvention(x, order, a, b)), (a, b)
-        assert np.abs(saf.convertHOANormConvention(y, order, b, a) - x).max() < 1e-6
-    sn = saf.convertHOANormConvention(x, order, 1, 2)                  # N3D -> SN3D divides order n by sqrt(2n+1)
+        assert np.abs(saf.convertHOANormConvention(y, order, b - 1, a - 1) - x).max() < 1e-6
+    sn = saf.convertHOANormConvention(x, order, 0, 1)                  # N3D -> SN3D divides order n by sqrt(2n+1)
     for n in range(order + 1):
         assert np.allclose(sn[n * n:(n + 1) ** 2], x[n * n:(n + 1) ** 2] / np.sqrt(np.float32(2 * n + 1)), rtol=1e-6)
     if order == 1:
         for a, b in ((1, 2), (2, 1)):
-            y = saf.convertHOAChannelConvention(x, order, a, b)
+            y = saf.convertHOAChannelConvention(x, order, a - 1, b - 1)
             assert np.array_equal(y, orc.convertHOAChannelConvention(x, order, a, b))
-            assert np.array_equal(saf.convertHOAChannelConvention(y, order, b, a), x)
-        assert np.array_equal(saf.convertHOAChannelConvention(x, 1, 1, 2), x[[0, 3, 1, 2]])        # ACN WYZX -> FuMa WXYZ
+            assert np.array_equal(saf.convertHOAChannelConvention(y, order, b - 1, a - 1), x)
+        assert np.array_equal(saf.convertHOAChannelConvention(x, 1, 0, 1), x[[0, 3, 1, 2]])        # ACN WYZX -> FuMa WXYZ
 
 
 def test_initCodec_on_second_thread_while_processing(saf):
