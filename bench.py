@@ -212,7 +212,7 @@ def run_rank(args):
                 "kernels_ms": {k: round(v[0], 5) for k, v in per.items()}, "note": note}
 
     EQK = ("afstft_eq", "band_gemm")
-    elapsed, general_kernels = timed_region(batch, 2, EQK, args.steps, args.warmup)
+    elapsed, general_kernels = timed_region(batch, args.path_mode, EQK if args.path_mode else ("afstft_analysis", "band_gemm", "afstft_synthesis"), args.steps, args.warmup)
     extra = {}
     if not args.no_extra_paths:
         w2 = max(2, args.warmup)
@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-extra-paths", action="store_true", help="only the headline timed region (used by the PMC passes)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short regions of the other BASELINE configs")
+    ap.add_argument("--path-mode", type=int, default=2, help="block path of the headline region (saf_hip_ambi_dec_setTimeDomainPath); profiling passes use 0 / 1")
     ap.add_argument("--dry-run", action="store_true", help="exercise launch / rendezvous / reduction with gloo, no GPU work (CPU tests)")
     ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--pin-core", type=int, default=None, help=argparse.SUPPRESS)

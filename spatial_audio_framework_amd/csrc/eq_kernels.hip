@@ -50,7 +50,7 @@ namespace saf {
 #define EQ_MINWAVES 3       /* waves per SIMD the one-output kernel is compiled for (168 registers) */
 #endif
 
-struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; };
+struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; int chunk; };
 
 template <int D>
 __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kernel(EqArgs g)
@@ -65,7 +65,15 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     const EqLaunch& e = g.e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ch = blockIdx.x, inst = blockIdx.y;
-    const int H = e.H, T = e.hopsPerFrame;
+    const int T = e.hopsPerFrame;
+    /* time chunks (grid z) add parallelism when few (channel, instance) workgroups exist: a chunk that does not start the launch
+     * first runs the 16 hops before it without emitting them, which rebuilds its overlap-add history (identical arithmetic:
+     * the outputs do not depend on how a launch is cut) */
+    const int c0 = blockIdx.z * g.chunk;                     /* first hop this workgroup emits */
+    const int H = min(c0 + g.chunk, e.H);                    /* end of its hops */
+    if (c0 >= H) return;
+    const int hs = c0 > 0 ? c0 - SUB : 0;                    /* first hop it processes (launch_eq keeps chunks >= 32 hops: hs >= 15) */
+    const bool last = H == e.H;                              /* the workgroup that owns the end of the launch records the state */
     const bool uni = e.uniform != nullptr && e.uniform[inst * SAF_MAXCH + ch] != 0;
 
     load_twiddles_pj(s_twJ, g.twJ, tid);
@@ -108,27 +116,32 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     for (int d = 0; d < D; d++) {
         const float* h = e.syn_rd + (long long)d * e.syn_d + ((long long)inst * e.nCh + ch) * SAF_SYN_HIST * 256;
 #pragma unroll
-        for (int i = 0; i < 9; i++) { gl[d][i] = h[i * 256 + tid]; gr[d][i] = h[i * 256 + 128 + tid]; }
+        for (int i = 0; i < 9; i++) { const float a = h[i * 256 + tid], b = h[i * 256 + 128 + tid]; gl[d][i] = c0 > 0 ? 0.0f : a; gr[d][i] = c0 > 0 ? 0.0f : b; }
 #pragma unroll
         for (int i = 9; i < EQ_OLA + 9; i++) gl[d][i] = gr[d][i] = 0.0f;
     }
 
     /* input cursor (uniform): element offset of the next hop inside this instance's input */
-    int curSub = 0;
-    long long curOff = 0;
+    const int hFirst = hs - SAF_ANA_HIST < 0 ? 0 : hs - SAF_ANA_HIST;      /* first hop read from the input buffer */
+    int curSub = hFirst % T;
+    long long curOff = (long long)(hFirst / T) * e.in_frame + curSub * SAF_HOP;
     auto advance = [&]() { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += e.in_frame - (long long)T * SAF_HOP; } };
 
-    /* the 15 hops before the launch and the first sub-chunk: one memory round trip */
+    /* the 15 hops before the first processed hop (state of the previous call, or — in a later chunk — the input itself) and the
+     * first sub-chunk: one memory round trip */
     float xin[SUB + 9], xw[6];
 #pragma unroll
     for (int i = 0; i < SAF_ANA_HIST; i++) {
-        const float v = hist[i * SAF_HOP];
+        const int h = hs - SAF_ANA_HIST + i;                 /* uniform */
+        float v;
+        if (h < 0) v = hist[(SAF_ANA_HIST + h) * SAF_HOP];
+        else { v = ld_in(inBase + curOff) * scale; advance(); }
         if (i < 6) xw[i] = v; else xin[i - 6] = v;
     }
 #pragma unroll
     for (int i = 0; i < SUB; i++) {
         xin[9 + i] = ld_in(inBase + curOff) * scale;
-        if (i + 1 < H) advance();
+        if (hs + i + 1 < H) advance();
     }
     __syncthreads();                                         /* s_gain, s_twJ */
     /* the gains carry the 1/2 of the real-FFT split and the 1/256 of the inverse transform (1/2 of the packing, 1/128 of
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     }
     const int hb = (lane & 3) + 1;                          /* hybrid items (wave 0): lane = (lagged hop u, bin b = 1..4) */
 
-    /* ---- prologue: hops -6 .. -1 (ring positions 0 .. 5): bins 1..4 for the hybrid FIR; hops -3 .. -1 are the first
+    /* ---- prologue: hops hs-6 .. hs-1 (ring positions 0 .. 5): bins 1..4 for the hybrid FIR; hops -3 .. -1 are the first
      *      three lagged slots of sub-chunk 0 ---- */
 #pragma unroll
     for (int t = 0; t < 6; t++) {
@@ -162,7 +175,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
         float* slot = s_ring + ff * SLOT;
         fft128_slot<false>(slot, fj, twJ, 0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (fj >= 1 && fj <= 4) s_low[(ff - 6 + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, s_twl[fj]);
+        if (fj >= 1 && fj <= 4) s_low[(hs + ff - 6 + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, s_twl[fj]);
     }
     lds_barrier();      /* the first fold below wraps into ring positions 0 and 1 (hops 14, 15): the warm-up FFTs must be done with them */
 
@@ -171,8 +184,9 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     for (int d = 0; d < D; d++) zBase[d] = e.z + (long long)d * e.z_d + (long long)inst * e.z_inst + (long long)ch * e.z_ch;
     int pN = 6;                                              /* ring position of hop s0 = (s0 + 6) % ERING */
 
-    for (int s0 = 0; s0 < H; s0 += SUB) {
+    for (int s0 = hs; s0 < H; s0 += SUB) {
         const int n = min(SUB, H - s0);
+        const bool emit = s0 >= c0;                         /* the warm-up sub-chunk of a later chunk only rebuilds the frame history */
         /* 1. window + fold of the new hops (afSTFT_internal.c:276-301) -> ring position (hop + 6) % ERING */
 #pragma unroll
         for (int t = 0; t < SUB; t++) {
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
         }
         /* the last sub-chunk records the new input history (the last 15 hops); a partial one re-reads them below */
         const bool more = s0 + SUB < H;
-        if (!more && n == SUB && e.hist_wr) {
+        if (!more && n == SUB && e.hist_wr && last) {
             float* dst = e.hist_wr + ((long long)inst * e.nCh + ch) * SAF_ANA_HIST * SAF_HOP + fn;
 #pragma unroll
             for (int row = 0; row < SAF_ANA_HIST; row++) dst[row * SAF_HOP] = xin[SUB + 9 - SAF_ANA_HIST + row];
@@ -318,7 +332,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
                             float acc = 0.0f;
 #pragma unroll
                             for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
-                            (zBase[d] + (long long)(s0 + uu) * SAF_HOP)[tid] = acc;
+                            if (emit) (zBase[d] + (long long)(s0 + uu) * SAF_HOP)[tid] = acc;
                         }
                     }
                     if (nh == EQ_OLA) {
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
         /* (no barrier: the next fold writes, and this overlap-add read, only the thread's own sample position of every slot) */
     }
 
-    if ((H % SUB) != 0 && e.hist_wr) {                      /* partial last sub-chunk: the last 15 hops of [old history | input] */
+    if (((H - hs) % SUB) != 0 && e.hist_wr && last) {       /* partial last sub-chunk: the last 15 hops of [old history | input] */
         int hh = H - SAF_ANA_HIST < 0 ? 0 : H - SAF_ANA_HIST;
         int fr = hh / T, sb = hh - fr * T;
         long long off = (long long)fr * e.in_frame + sb * SAF_HOP;
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
             if (h >= 0) { sb++; off += SAF_HOP; if (sb == T) { sb = 0; off += e.in_frame - (long long)T * SAF_HOP; } }
         }
     }
-    if (e.syn_wr) {
+    if (e.syn_wr && last) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
             float* h = e.syn_wr + (long long)d * e.syn_d + ((long long)inst * e.nCh + ch) * SAF_SYN_HIST * 256;
@@ -374,7 +388,16 @@ void launch_eq(const EqLaunch& e)
     g.win = dev_window(0, 0);
     g.twJ = dev_twiddles();
     g.tw256 = g.twJ + 128;
-    const dim3 grid(e.nCh, e.nInst);
+    /* time chunks only when the (channel, instance) grid leaves most of the chip idle: every extra chunk processes 16 more hops.
+     * Aim at ~1024 workgroups with chunks of >= 64 hops (multiples of 16). */
+    g.chunk = e.H;
+    const long long wgs = (long long)e.nCh * e.nInst;
+    if (wgs < 512 && e.H >= 128) {
+        int nChunks = (int)((1024 + wgs - 1) / wgs);
+        if (nChunks > e.H / 64) nChunks = e.H / 64;
+        if (nChunks > 1) g.chunk = ((e.H + nChunks - 1) / nChunks + SUB - 1) / SUB * SUB;
+    }
+    const dim3 grid(e.nCh, e.nInst, (e.H + g.chunk - 1) / g.chunk);
     KernelTimer kt("afstft_eq");
     if (e.D == 1) hipLaunchKernelGGL(afstft_eq_kernel<1>, grid, dim3(128), 0, stream(), g);
     else          hipLaunchKernelGGL(afstft_eq_kernel<2>, grid, dim3(128), 0, stream(), g);

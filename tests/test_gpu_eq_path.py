@@ -155,6 +155,37 @@ def test_equaliser_path_batch_split_invariance_and_strides(saf, orc, path):
     saf.set_stream(None)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_equaliser_path_time_chunks_bit_identical(saf, orc, path, mode):
+    """one handle rendering many blocks per call: the launch is cut into time chunks (few (channel, instance) workgroups);
+    a chunk rebuilds its overlap-add history from the 16 hops before it.  Bit-identical to the same stream in short calls
+    (no chunks), and equal to the oracle."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    F, order, nF = 512, 7, 44                     # 176 hops in one call -> 2 chunks of 96 / 80 hops
+    path(mode)
+    orders = band_orders(7, 4)
+    x = frames(640, nF * 64, 512).reshape(1, nF, 64, 512)
+    d_in = torch.from_numpy(x).cuda()
+    st = (nF * 64 * 512, 64 * 512, 512)
+    outs = []
+    for split in ((nF,), (11, 11, 11, 11), (1, 43)):
+        bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, 1, 1, 1, 1, orders)], nF)
+        d_out = torch.zeros(1, nF, 64, 512, device="cuda")
+        f0 = 0
+        for n in split:
+            bt.process_ptr(d_in[:, f0:].data_ptr(), st, d_out[:, f0:].data_ptr(), st, n)
+            f0 += n
+        torch.cuda.synchronize()
+        assert bt.lastPath() == 1
+        outs.append(d_out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    o = make(orc.AmbiDec, F, order, 29, 1, 1, 1, 1, orders)
+    yo = np.stack([o.process(x[0, f], 64) for f in range(12)])
+    assert relrms(outs[0][0, :12], yo) < 3e-6
+    saf.set_stream(None)
+
+
 def test_equaliser_path_full_size_properties(saf, path):
     """bench size (256 instances x 64 blocks, every band its own order): linearity, instance independence, split invariance,
     and agreement with the transform path — the oracle is too slow here"""

@@ -6,12 +6,12 @@ set -e
 TAG=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_traced.json 2> $R/gpurun_out/${TAG}_trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_trace -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-other-configs > $R/gpurun_out/${TAG}_bench_traced.json 2> $R/gpurun_out/${TAG}_trace.err
 cp $(find $R/gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/${TAG}_pmc_$C -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile --no-band-independent > /dev/null 2> $R/gpurun_out/${TAG}_pmc_$C.err
+  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/${TAG}_pmc_$C -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile --no-extra-paths > /dev/null 2> $R/gpurun_out/${TAG}_pmc_$C.err
 done
-python3 $R/tools/traffic_summary.py --frames-per-launch=16384 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE $R/gpurun_out/${TAG}_pmc_WRITE_SIZE > $R/gpurun_out/${TAG}_traffic.json
+TRAFFIC_SOURCE="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes of bench.py --steps 6 --no-extra-paths, tools/gpu_profile.sh ${TAG}" python3 $R/tools/traffic_summary.py --frames-per-launch=16384 $R/gpurun_out/${TAG}_pmc_FETCH_SIZE $R/gpurun_out/${TAG}_pmc_WRITE_SIZE > $R/gpurun_out/${TAG}_traffic.json
 cat $R/gpurun_out/${TAG}_traffic.json
 cd $R
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err

@@ -11,6 +11,8 @@ READ_CORR = {   # kernel -> (factor, note)
     "band_gemm_kernel": (2.0, "16 B/lane loads: FETCH_SIZE x 2 (guide)"),
     "afstft_synthesis_ws_kernel": (2.0, "8 B/lane loads: x 2 (matches the algorithmic bytes; width not covered by the guide)"),
     "afstft_analysis_kernel": (2.0, "4 B/lane loads, 256 B contiguous per wave: x 2 (face value would be below the input bytes alone)"),
+    "afstft_eq_kernel": (2.0, "4 B/lane loads, 256 B contiguous per wave: x 2 (as the analysis kernel; face value would be below the input bytes alone)"),
+    "band_gemm2_kernel": (2.0, "16 B/lane loads: FETCH_SIZE x 2 (guide)"),
 }
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 frames_per_launch = None
@@ -22,8 +24,9 @@ for d in args:
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0].split("<")[0].replace("saf::", "").replace("void ", "")
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-out = {"frames_per_launch": frames_per_launch}
-names = {"afstft_analysis_kernel": "afstft_analysis", "band_gemm_kernel": "band_gemm", "afstft_synthesis_ws_kernel": "afstft_synthesis"}
+out = {"frames_per_launch": frames_per_launch, "source": os.environ.get("TRAFFIC_SOURCE", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/gpu_profile.sh")}
+names = {"afstft_eq_kernel": "afstft_eq", "afstft_analysis_kernel": "afstft_analysis", "band_gemm_kernel": "band_gemm", "band_gemm2_kernel": "band_gemm2",
+         "afstft_synthesis_ws_kernel": "afstft_synthesis"}
 for k, short in names.items():
     if k not in acc:
         continue
