@@ -178,6 +178,8 @@ def run_rank(args):
     y = torch.zeros(nI, nF, NCH, FRAME, device=dev)
     st = (nF * NCH * FRAME, NCH * FRAME, FRAME)
 
+    region_events_ms = {}
+
     def timed_region(bt, mode, kernels, steps, warmup):
         """`steps` timed passes on block path `mode` (saf_hip_ambi_dec_setTimeDomainPath) from a cleared filterbank state;
         returns (max-over-ranks seconds, {kernel: (avg launch ms, launches)})"""
@@ -188,14 +190,18 @@ def run_rank(args):
         torch.cuda.synchronize()
         L.saf_hip_profile_reset()
         L.saf_hip_profile_enable(0 if args.no_profile else 1)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # the library launches on torch's current stream (api.set_stream above)
         P.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        ev0.record()
         for i in range(steps):
             bt.process_ptr(xs[i & 1].data_ptr(), st, y.data_ptr(), st, nF)
+        ev1.record()
         torch.cuda.synchronize()
         P.barrier()
         dt = time.perf_counter() - t0
+        region_events_ms[mode] = ev0.elapsed_time(ev1)
         L.saf_hip_profile_enable(0)
         dt = P.max_over_ranks(dt, device=dev)
         per = {}
@@ -299,6 +305,8 @@ def run_rank(args):
                        "instances_per_gpu": nI, "frames_per_step_per_instance": nF, "frames_per_step_per_gpu": nI * nF,
                        "parallelism": f"independent instances sharded over {world} GPU(s), no collective on the data path"},
             "roofline": roof, "cpu_baseline": cpu, "cpu_baseline_allcores": cpu_all,
+            "timed_region_check": {"host_clock_ms": round(1e3 * elapsed, 3), "hip_events_ms": round(region_events_ms.get(args.path_mode, 0.0), 3),
+                                   "note": "the K timed steps between the barriers, by the host clock (used for `value`) and by two HIP events on the launch stream"},
         }
         line.update(extra)
         if other is not None:

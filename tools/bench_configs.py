@@ -158,7 +158,7 @@ def main():
     def step5():
         eb.process_ptr(x.data_ptr(), st, nS, sh.data_ptr(), st, 64, nF)
         db.process_ptr(sh.data_ptr(), st, ls.data_ptr(), st, nF)
-    t, per = timed(L, torch, step5, steps, warm, ["sh_encode", "afstft_analysis", "band_gemm", "afstft_synthesis"])
+    t, per = timed(L, torch, step5, steps, warm, ["sh_encode", "afstft_eq", "afstft_analysis", "band_gemm", "afstft_synthesis"])
     oe, od = mke(O.AmbiEnc, 0), mkd(O.AmbiDec); xb = frames(5, nS, F)
     tc = cpu_time(lambda: od.process(oe.process(xb, 64), 64), 6.0)
     out.append({"config": "2048 sources = 32 scenes x 64 sources on ONE GPU: ambi_enc (order 7) -> ambi_dec (64 loudspeakers), 512-sample blocks (configs[4], per-GPU share x 8)",
