@@ -48,6 +48,10 @@ SAF_API const char* saf_hip_version(void);
 SAF_API void saf_hip_profile_enable(int on);
 SAF_API void saf_hip_profile_reset(void);
 SAF_API int  saf_hip_profile_read(const char* kernelName, double* total_ms);
+/** Two HIP events on the library stream: start() records the first, stop_ms() records the second, waits for it and returns
+ *  the time between them (what the device spent on everything the library enqueued in between). */
+SAF_API void   saf_hip_stopwatch_start(void);
+SAF_API double saf_hip_stopwatch_stop_ms(void);
 
 /* ========================================================================== */
 /*      afSTFT  (framework/resources/afSTFT/afSTFTlib.h:85-278)               */

@@ -44,6 +44,7 @@ def load():
         f.argtypes = list(args)
 
     sig("saf_hip_set_stream", None, vp)
+    sig("saf_hip_stopwatch_start", None); sig("saf_hip_stopwatch_stop_ms", C.c_double)
     sig("saf_hip_setZeroCopyIO", None, ci); sig("saf_hip_getZeroCopyIO", ci)
     sig("saf_hip_get_stream", vp)
     sig("saf_hip_synchronize", None)

@@ -111,6 +111,23 @@ int saf_hip_profile_read(const char* name, double* total_ms)
     return n;
 }
 
+/* a stop-watch on the library stream (bench.py corroborates its host-clock timing with it) */
+static hipEvent_t g_sw0 = nullptr, g_sw1 = nullptr;
+void saf_hip_stopwatch_start(void)
+{
+    if (!g_sw0) { HIP_CHECK(hipEventCreate(&g_sw0)); HIP_CHECK(hipEventCreate(&g_sw1)); }
+    HIP_CHECK(hipEventRecord(g_sw0, saf::stream()));
+}
+double saf_hip_stopwatch_stop_ms(void)
+{
+    if (!g_sw0) return 0.0;
+    HIP_CHECK(hipEventRecord(g_sw1, saf::stream()));
+    HIP_CHECK(hipEventSynchronize(g_sw1));
+    float ms = 0.f;
+    HIP_CHECK(hipEventElapsedTime(&ms, g_sw0, g_sw1));
+    return (double)ms;
+}
+
 void saf_hip_setZeroCopyIO(int enable) { saf::g_zero_copy = enable ? 1 : 0; }
 int saf_hip_getZeroCopyIO(void) { return saf::g_zero_copy; }
 void saf_hip_set_stream(void* hipStream) { saf::set_stream((hipStream_t)hipStream); }
