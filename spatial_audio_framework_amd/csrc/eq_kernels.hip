@@ -50,7 +50,12 @@ namespace saf {
 #define EQ_MINWAVES 3       /* waves per SIMD the one-output kernel is compiled for (168 registers) */
 #endif
 
-struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; int chunk; };
+struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; int chunk; unsigned long long* stamps; };
+#ifdef EQ_STAMPS        /* diagnostic build only: cycles per phase of every 64th workgroup (tools/eq_stamps.py) */
+#define STAMP(i) do { if (stampOn && lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += t_ - stampT; stampT = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 template <int D>
 __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kernel(EqArgs g)
@@ -92,11 +97,23 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     const unsigned offInB = (unsigned)((chValid ? srcch : 0) * e.in_ch + fn) * 4u;      /* launch_eq checks the extent */
     const float* inBase = e.in + (long long)inst * e.in_inst;
     const float* hist = e.hist_rd + ((long long)inst * e.nCh + ch) * (SAF_ANA_HIST * SAF_HOP) + fn;
-    auto ld_in = [&](const float* base) {       /* uniform 64-bit base in scalar registers + 32-bit byte offset per lane */
-        const unsigned long long b = (unsigned long long)base;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo) + offInB);
+    /* Input addressing: hop h of this instance starts at float index (h / T) * in_frame + (h % T) * 128.  The offsets of 16
+     * consecutive hops are computed by 16 lanes at once (float reciprocal: exact for h < 2^22, checked by launch_eq) and
+     * handed out with v_readlane; every load is  uniform 64-bit base + 32-bit byte offset per lane.  (A scalar cursor with
+     * its wrap test per hop cost ~360 scalar instructions and 36 branches per sub-chunk: a seventh of the wave's issue slots.) */
+    const float invT = 1.0f / (float)T;
+    const int inFrame = (int)e.in_frame;
+    auto hop_off_bytes = [&](int h) {                       /* per lane */
+        const int fr = (int)(((float)h + 0.5f) * invT);
+        return (unsigned)(fr * inFrame + (h - fr * T) * SAF_HOP) * 4u;
     };
+    const char* inBaseB;                                    /* uniform: pinned to scalar registers */
+    {
+        const unsigned long long b = (unsigned long long)inBase;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        inBaseB = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    }
+    auto ld_at = [&](unsigned hopOffBytes) { return *reinterpret_cast<const float*>(inBaseB + (hopOffBytes + offInB)); };
     float w[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) w[k] = g.win[k * SAF_HOP + fn];
@@ -106,9 +123,10 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     const TwCol twJ{ s_twJ + fj };
 
     /* ---- main-pass role: lane = bin pair (k, 128-k), k = lane + 1 ---- */
-    const int mk = lane + 1;
-    const float2 Wk = g.tw256[mk];
-    float gk[D], gm[D];
+    const int mk = lane == 0 ? 0 : lane + 1;                 /* lane 0: DC / Nyquist (k = 0); lanes 1..3 idle (bins 2..4 are hybrid items) */
+    const bool mkOn = lane == 0 || lane >= 4;
+    const bool mkPair = lane >= 4 && lane != 63;             /* writes Z'[128-k] too (not for k = 0 and k = 64: their partner is themselves) */
+    float ca[D], cb[D], cg[D];                               /* the pair's 2 x 2 real map, see below */
 
     /* ---- overlap-add role: thread = sample position; frame history of the 9 hops before the launch ---- */
     float gl[D][EQ_OLA + 9], gr[D][EQ_OLA + 9];
@@ -122,37 +140,49 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     }
 
     /* input cursor (uniform): element offset of the next hop inside this instance's input */
-    const int hFirst = hs - SAF_ANA_HIST < 0 ? 0 : hs - SAF_ANA_HIST;      /* first hop read from the input buffer */
-    int curSub = hFirst % T;
-    long long curOff = (long long)(hFirst / T) * e.in_frame + curSub * SAF_HOP;
-    auto advance = [&]() { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += e.in_frame - (long long)T * SAF_HOP; } };
-
     /* the 15 hops before the first processed hop (state of the previous call, or — in a later chunk — the input itself) and the
      * first sub-chunk: one memory round trip */
     float xin[SUB + 9], xw[6];
+    {
+        const int hq = hs - SAF_ANA_HIST + (lane & 15);     /* lanes 0..14: the history hops */
+        const unsigned offH = hop_off_bytes(hq < 0 ? 0 : hq);
+        const unsigned offN = hop_off_bytes(min(hs + (lane & 15), H - 1));      /* hops beyond the end re-read the last one (never used) */
 #pragma unroll
-    for (int i = 0; i < SAF_ANA_HIST; i++) {
-        const int h = hs - SAF_ANA_HIST + i;                 /* uniform */
-        float v;
-        if (h < 0) v = hist[(SAF_ANA_HIST + h) * SAF_HOP];
-        else { v = ld_in(inBase + curOff) * scale; advance(); }
-        if (i < 6) xw[i] = v; else xin[i - 6] = v;
-    }
+        for (int i = 0; i < SAF_ANA_HIST; i++) {
+            const int h = hs - SAF_ANA_HIST + i;             /* uniform */
+            float v;
+            if (h < 0) v = hist[(SAF_ANA_HIST + h) * SAF_HOP];
+            else v = ld_at(__builtin_amdgcn_readlane(offH, i)) * scale;
+            if (i < 6) xw[i] = v; else xin[i - 6] = v;
+        }
 #pragma unroll
-    for (int i = 0; i < SUB; i++) {
-        xin[9 + i] = ld_in(inBase + curOff) * scale;
-        if (hs + i + 1 < H) advance();
+        for (int i = 0; i < SUB; i++) xin[9 + i] = ld_at(__builtin_amdgcn_readlane(offN, i)) * scale;
     }
     __syncthreads();                                         /* s_gain, s_twJ */
-    /* the gains carry the 1/2 of the real-FFT split and the 1/256 of the inverse transform (1/2 of the packing, 1/128 of
-     * saf_rfft_backward, saf_utility_fft.c:751): powers of two, so nothing changes in the rounding */
+    /* Bins k and 128-k (k >= 5) between the forward and the inverse transform: real-FFT split (kiss_fftr.c:86-123), the gains
+     * g_k, g_m of their two bands, half-complex packing (kiss_fftr.c:125-161).  With a = Z[k], b = conj Z[128-k], W = e^{-2 pi i k/256}:
+     *     2 X[k] = a (1 - iW) + b (1 + iW),      2 X[128-k] = conj( a (1 + iW) + b (1 - iW) )
+     *     Z'[k] = B_k (1 + i W*) + conj(B_m) (1 - i W*),   Z'[128-k] = conj( B_k (1 - i W*) + conj(B_m) (1 + i W*) ),   B = g X
+     * and because |W| = 1 every product of the brackets is real or purely imaginary:
+     *     Z'[k]     = alpha Z[k]     + i beta conj Z[128-k],     alpha = g_k (1 + Im W) + g_m (1 - Im W)
+     *     Z'[128-k] = gamma Z[128-k] + i beta conj Z[k],         gamma = g_k (1 - Im W) + g_m (1 + Im W),   beta = Re W (g_k - g_m)
+     * — eight multiply-adds per pair instead of the split / scale / pack sequence (28).  The gains carry the 1/2 of the split
+     * and the 1/256 of the inverse transform (1/2 of the packing, 1/128 of saf_rfft_backward, saf_utility_fft.c:751). */
     const float GS = 1.0f / 256.0f;
     float sc[D];
+    {
+        const float2 Wk = g.tw256[mk];
 #pragma unroll
-    for (int d = 0; d < D; d++) {
-        gk[d] = 0.5f * GS * s_gain[d][mk + 4];              /* band of bin k >= 5 is k + 4 (lanes k < 5 idle in the bin phase) */
-        gm[d] = 0.5f * GS * s_gain[d][132 - mk];            /* band of bin 128 - k */
-        sc[d] = uni ? s_gain[d][0] : 1.0f;                  /* frame scale of the overlap-add */
+        for (int d = 0; d < D; d++) {
+            const float gkd = GS * s_gain[d][mk == 0 ? 0 : mk + 4];           /* band of bin k >= 5 is k + 4; bin 0 is band 0 */
+            const float gmd = GS * s_gain[d][132 - mk];                       /* band of bin 128 - k (k = 0: the Nyquist band 132) */
+            /* k = 0: Z[0] packs the two real bins: X[0] = Re + Im, X[128] = Re - Im, and back Z'[0] = (B0 + B128, B0 - B128):
+             * the same 2 x 2 map with Z[128-k] := Z[0], alpha = g_0 + g_132, beta = g_0 - g_132 */
+            ca[d] = mk == 0 ? gkd + gmd : gkd * (1.0f + Wk.y) + gmd * (1.0f - Wk.y);
+            cg[d] = gkd * (1.0f - Wk.y) + gmd * (1.0f + Wk.y);
+            cb[d] = mk == 0 ? gkd - gmd : Wk.x * (gkd - gmd);
+            sc[d] = uni ? s_gain[d][0] : 1.0f;              /* frame scale of the overlap-add */
+        }
     }
     const int hb = (lane & 3) + 1;                          /* hybrid items (wave 0): lane = (lagged hop u, bin b = 1..4) */
 
@@ -183,9 +213,17 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
 #pragma unroll
     for (int d = 0; d < D; d++) zBase[d] = e.z + (long long)d * e.z_d + (long long)inst * e.z_inst + (long long)ch * e.z_ch;
     int pN = 6;                                              /* ring position of hop s0 = (s0 + 6) % ERING */
+#ifdef EQ_STAMPS
+    const bool stampOn = g.stamps != nullptr && ((blockIdx.y * gridDim.x + blockIdx.x) & 63) == 0;
+    unsigned long long stampAcc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, stampT = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int s0 = hs; s0 < H; s0 += SUB) {
         const int n = min(SUB, H - s0);
+        if (s0 > hs) {                                       /* the hops requested at the end of the previous iteration */
+#pragma unroll
+            for (int i = 0; i < SUB; i++) xin[9 + i] *= scale;
+        }
         const bool emit = s0 >= c0;                         /* the warm-up sub-chunk of a later chunk only rebuilds the frame history */
         /* 1. window + fold of the new hops (afSTFT_internal.c:276-301) -> ring position (hop + 6) % ERING */
 #pragma unroll
@@ -206,21 +244,15 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
 #pragma unroll
             for (int row = 0; row < SAF_ANA_HIST; row++) dst[row * SAF_HOP] = xin[SUB + 9 - SAF_ANA_HIST + row];
         }
-        /* slide the window, prefetch the next sub-chunk (consumed before the output stores of phase 5: vmcnt is in order) */
+        /* slide the window */
 #pragma unroll
         for (int i = 0; i < 9; i++) xin[i] = xin[i + SUB];
-        float xl[SUB];
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < SUB; i++) {
-                xl[i] = ld_in(inBase + curOff);
-                if (s0 + SUB + i + 1 < H) advance();
-            }
-        }
         const int pL = pN >= 3 ? pN - 3 : pN - 3 + ERING;      /* ring position of the first lagged hop s0 - 3 */
         auto lag_slot = [&](int u) { const int pos = pL + u >= ERING ? pL + u - ERING : pL + u; return s_ring + pos * SLOT; };
+        STAMP(0);                                            /* fold */
         if (!uni) {
             lds_barrier();                                   /* B1 */
+            STAMP(1);
             /* 2. 256-point real FFT as a 128-point complex FFT, in place; bins 1..4 of the new hop -> s_low */
             if (ff < n) {
                 float* slot = s_ring + (pN + ff >= ERING ? pN + ff - ERING : pN + ff) * SLOT;
@@ -228,92 +260,95 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 if (fj >= 1 && fj <= 4) s_low[(s0 + ff + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, s_twl[fj]);
             }
+            STAMP(2);                                        /* FFT */
             lds_barrier();                                   /* B2 */
-            /* 3. bins k and 128-k of the lagged slots (lagged hop hl = s0 - 3 + u): real-FFT split (kiss_fftr.c:86-123), gains,
-             *    half-complex packing (kiss_fftr.c:125-161), in place.  2 Z'[k] = E + i O, 2 Z'[128-k] = conj(E - i O) with
-             *    E = B[k] + conj B[128-k], O = (B[k] - conj B[128-k]) e^{+2 pi i k / 256}. */
-            auto bin_pair = [&](float* slot, int u, int k, float2 W, const float (&ga)[D], const float (&gb)[D], bool hybrid, const float2 (&Bh)[D]) {
-                const float2 Zk = *reinterpret_cast<const float2*>(slot + 2 * k);
-                const float2 Zm = *reinterpret_cast<const float2*>(slot + 2 * (128 - k));
-                const float2 ee = make_float2(Zk.x + Zm.x, Zk.y - Zm.y);
-                const float2 dd = make_float2(Zk.x - Zm.x, Zk.y + Zm.y);
-                const float2 tt = cmul(W, dd);
-                const float2 Xk = make_float2(ee.x + tt.y, ee.y - tt.x);          /* 2 X[k] */
-                const float2 Xm = make_float2(ee.x - tt.y, -ee.y - tt.x);         /* 2 X[128-k] */
+            STAMP(3);
+            /* 3. bins of the wave's lagged slots 8 wv .. 8 wv + 7 (lagged hop hl = s0 - 3 + u), in place.  Every item reads and
+             *    writes only its own two elements of the slot, so the items need no order among themselves.
+             *    Hybrid items, lane = (slot u, bin b = 1..4) (afSTFT_internal.c:595-619): band 2b-1 / 2b = 0.5 S_{hl}[b] -/+ (or +/-) g_b,
+             *    g_b = i (C1 (S_{hl+3} - S_{hl-3}) + C2 (S_{hl+1} - S_{hl-1})); the gains of the two half-bands, their sum
+             *    (afHybridInverse, :625-653) = B[b]; then split / gain / pack against bin 128-b as in the general case:
+             *    2 Z'[b] = E + i O, 2 Z'[128-b] = conj(E - i O), E = B[b] + conj B[128-b], O = (B[b] - conj B[128-b]) e^{+2 pi i b / 256}.
+             *    Written branch-free (all lanes compute, lanes 32..63 shadow lanes 0..31, only the stores are guarded) and with
+             *    its loads first: as a guarded block it was four dependent LDS round trips = 15 % of the sub-chunk. */
+            const int uh = 8 * wv + ((lane >> 2) & 7);
+            const bool hOn = lane < 32 && uh < n;
+            float* hslot = lag_slot(uh < n ? uh : 0);
+            const int hl = s0 - 3 + uh + 64;
+            const float2 hDk = s_low[hl & (LOWR - 1)][hb - 1];
+            const float2 hS0 = s_low[(hl + 3) & (LOWR - 1)][hb - 1], hS2 = s_low[(hl + 1) & (LOWR - 1)][hb - 1];
+            const float2 hS4 = s_low[(hl - 1) & (LOWR - 1)][hb - 1], hS6 = s_low[(hl - 3) & (LOWR - 1)][hb - 1];
+            const float2 hZk = *reinterpret_cast<const float2*>(hslot + 2 * hb);
+            const float2 hZm = *reinterpret_cast<const float2*>(hslot + 2 * (128 - hb));
+            const float2 hW = s_twl[hb];
+            float hg1[D], hg2[D], hgm[D];
 #pragma unroll
-                for (int d = 0; d < D; d++) {
-                    const float2 Bk = hybrid ? Bh[d] : make_float2(ga[d] * Xk.x, ga[d] * Xk.y);
-                    const float2 Bm = make_float2(gb[d] * Xm.x, gb[d] * Xm.y);
-                    const float2 E = make_float2(Bk.x + Bm.x, Bk.y - Bm.y);
-                    const float2 Dd = make_float2(Bk.x - Bm.x, Bk.y + Bm.y);
-                    const float2 O = make_float2(Dd.x * W.x + Dd.y * W.y, Dd.y * W.x - Dd.x * W.y);      /* Dd * conj(W) */
-                    float* o = d == 0 ? slot : s_out1 + u * SLOT;
-                    *reinterpret_cast<float2*>(o + 2 * k) = make_float2(E.x - O.y, E.y + O.x);
-                    if (k != 64) *reinterpret_cast<float2*>(o + 2 * (128 - k)) = make_float2(E.x + O.y, O.x - E.y);
-                }
-            };
-            /* a wave owns the lagged slots 8 wv .. 8 wv + 7 through phases 3 and 4 */
-            if (lane < 32) {
-                /* hybrid bins (afSTFT_internal.c:595-619): band 2b-1 / 2b = 0.5 S_{hl}[b] -/+ (or +/-) g_b,
-                 * g_b = i (C1 (S_{hl+3} - S_{hl-3}) + C2 (S_{hl+1} - S_{hl-1})); then the gains of the two half-bands and their sum
-                 * (afHybridInverse, :625-653) */
-                const int u = 8 * wv + (lane >> 2);
-                if (u < n) {
-                    const int hl = s0 - 3 + u + 64;
-                    const float2 Dk = s_low[hl & (LOWR - 1)][hb - 1];
-                    const float2 S0 = s_low[(hl + 3) & (LOWR - 1)][hb - 1], S2 = s_low[(hl + 1) & (LOWR - 1)][hb - 1];
-                    const float2 S4 = s_low[(hl - 1) & (LOWR - 1)][hb - 1], S6 = s_low[(hl - 3) & (LOWR - 1)][hb - 1];
-                    float gre, gim;
-                    gre = -COEFF1 * S0.y;          gim = COEFF1 * S0.x;
-                    gre -= COEFF2 * S2.y;          gim += COEFF2 * S2.x;
-                    gre += COEFF2 * S4.y;          gim -= COEFF2 * S4.x;
-                    gre += COEFF1 * S6.y;          gim -= COEFF1 * S6.x;
-                    const float dr = Dk.x * 0.5f, di = Dk.y * 0.5f;
-                    const float sgn = (hb & 1) ? -1.0f : 1.0f;
-                    const float2 lo = make_float2(dr + sgn * gre, di + sgn * gim), hi = make_float2(dr - sgn * gre, di - sgn * gim);
-                    float2 Bh[D]; float ghm[D];
-#pragma unroll
-                    for (int d = 0; d < D; d++) {
-                        const float gh1 = GS * s_gain[d][2 * hb - 1], gh2 = GS * s_gain[d][2 * hb];
-                        ghm[d] = 0.5f * GS * s_gain[d][132 - hb];
-                        Bh[d] = make_float2(gh1 * lo.x + gh2 * hi.x, gh1 * lo.y + gh2 * hi.y);
-                    }
-                    bin_pair(lag_slot(u), u, hb, s_twl[hb], ghm, ghm, true, Bh);
-                }
-            } else if (lane < 40) {
-                /* DC and Nyquist: X[0] = Re Z[0] + Im Z[0], X[128] = Re Z[0] - Im Z[0]; packed back as (B0 + B128, B0 - B128) */
-                const int u = 8 * wv + lane - 32;
-                if (u < n) {
-                    float* slot = lag_slot(u);
-                    const float2 Z0 = *reinterpret_cast<const float2*>(slot);
-                    const float X0 = Z0.x + Z0.y, X128 = Z0.x - Z0.y;
-#pragma unroll
-                    for (int d = 0; d < D; d++) {
-                        const float B0 = GS * s_gain[d][0] * X0, B128 = GS * s_gain[d][132] * X128;
-                        float* o = d == 0 ? slot : s_out1 + u * SLOT;
-                        *reinterpret_cast<float2*>(o) = make_float2(B0 + B128, B0 - B128);
-                    }
-                }
-            }
-            if (mk >= 5) {
-                const float2 none[D] = {};
-#pragma unroll 2
+            for (int d = 0; d < D; d++) { hg1[d] = GS * s_gain[d][2 * hb - 1]; hg2[d] = GS * s_gain[d][2 * hb]; hgm[d] = 0.5f * GS * s_gain[d][132 - hb]; }
+            /* general items: lane = bin pair (k, 128-k), see the derivation of ca / cb / cg above */
+            if (mkOn) {
+#pragma unroll 4
                 for (int i = 0; i < SUB / 2; i++) {
                     const int u = 8 * wv + i;
-                    if (u < n) bin_pair(lag_slot(u), u, mk, Wk, gk, gm, false, none);
+                    if (u < n) {
+                        float* slot = lag_slot(u);
+                        const float2 Zk = *reinterpret_cast<const float2*>(slot + 2 * mk);
+                        const float2 Zm = *reinterpret_cast<const float2*>(slot + 2 * ((128 - mk) & 127));
+#pragma unroll
+                        for (int d = 0; d < D; d++) {
+                            float* o = d == 0 ? slot : s_out1 + u * SLOT;
+                            *reinterpret_cast<float2*>(o + 2 * mk) = make_float2(fmaf(ca[d], Zk.x, cb[d] * Zm.y), fmaf(ca[d], Zk.y, cb[d] * Zm.x));
+                            if (mkPair) *reinterpret_cast<float2*>(o + 2 * (128 - mk)) = make_float2(fmaf(cg[d], Zm.x, cb[d] * Zk.y), fmaf(cg[d], Zm.y, cb[d] * Zk.x));
+                        }
+                    }
                 }
             }
+            {
+                float gre, gim;
+                gre = -COEFF1 * hS0.y;          gim = COEFF1 * hS0.x;
+                gre -= COEFF2 * hS2.y;          gim += COEFF2 * hS2.x;
+                gre += COEFF2 * hS4.y;          gim -= COEFF2 * hS4.x;
+                gre += COEFF1 * hS6.y;          gim -= COEFF1 * hS6.x;
+                const float dr = hDk.x * 0.5f, di = hDk.y * 0.5f;
+                const float sgn = (hb & 1) ? -1.0f : 1.0f;
+                const float2 lo = make_float2(dr + sgn * gre, di + sgn * gim), hi = make_float2(dr - sgn * gre, di - sgn * gim);
+                const float2 ee = make_float2(hZk.x + hZm.x, hZk.y - hZm.y);
+                const float2 dd = make_float2(hZk.x - hZm.x, hZk.y + hZm.y);
+                const float2 tt = cmul(hW, dd);
+                const float2 Xm = make_float2(ee.x - tt.y, -ee.y - tt.x);         /* 2 X[128-b] */
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    const float2 Bk = make_float2(hg1[d] * lo.x + hg2[d] * hi.x, hg1[d] * lo.y + hg2[d] * hi.y);
+                    const float2 Bm = make_float2(hgm[d] * Xm.x, hgm[d] * Xm.y);
+                    const float2 E = make_float2(Bk.x + Bm.x, Bk.y - Bm.y);
+                    const float2 Dd = make_float2(Bk.x - Bm.x, Bk.y + Bm.y);
+                    const float2 O = make_float2(Dd.x * hW.x + Dd.y * hW.y, Dd.y * hW.x - Dd.x * hW.y);      /* Dd * conj(W) */
+                    if (hOn) {
+                        float* o = d == 0 ? hslot : s_out1 + uh * SLOT;
+                        *reinterpret_cast<float2*>(o + 2 * hb) = make_float2(E.x - O.y, E.y + O.x);
+                        *reinterpret_cast<float2*>(o + 2 * (128 - hb)) = make_float2(E.x + O.y, O.x - E.y);
+                    }
+                }
+            }
+            STAMP(4);                                        /* bins */
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             /* 4. inverse FFT of the wave's own 8 slots, in place: frame samples 2m, 2m+1 = Re, Im z[m] */
             if (ff < n) {
                 fft128_slot<true>(lag_slot(ff), fj, twJ, 0);
                 if (D > 1) fft128_slot<true>(s_out1 + ff * SLOT, fj, twJ, 0);
             }
+            STAMP(5);                                        /* IFFT */
             lds_barrier();                                   /* B3 */
+            STAMP(6);
         }
+        /* The next sub-chunk's input is requested HERE, into the dead upper part of the window, and first used by the next fold:
+         * in flight under the overlap-add.  Not earlier: 16 more live registers across the two FFT phases spill, and every
+         * reload of a spilled register is a vector-memory load whose wait (vmcnt is in order) also waits for these 16 loads —
+         * measured as 4 000 idle cycles per sub-chunk in the bin phase.  The output stores below are younger than the loads, so
+         * the fold's wait for the loads does not wait for them. */
         if (more) {
+            const unsigned offN = hop_off_bytes(min(s0 + SUB + (lane & 15), H - 1));
 #pragma unroll
-            for (int i = 0; i < SUB; i++) xin[9 + i] = xl[i] * scale;
+            for (int i = 0; i < SUB; i++) xin[9 + i] = ld_at(__builtin_amdgcn_readlane(offN, i));
         }
         /* 5. 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0 + t is
          *    sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n] */
@@ -350,23 +385,24 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
                 }
             }
         }
+        STAMP(7);                                            /* prefetch wait + OLA + stores */
         pN = pN + SUB >= ERING ? pN + SUB - ERING : pN + SUB;
         /* (no barrier: the next fold writes, and this overlap-add read, only the thread's own sample position of every slot) */
     }
 
     if (((H - hs) % SUB) != 0 && e.hist_wr && last) {       /* partial last sub-chunk: the last 15 hops of [old history | input] */
-        int hh = H - SAF_ANA_HIST < 0 ? 0 : H - SAF_ANA_HIST;
-        int fr = hh / T, sb = hh - fr * T;
-        long long off = (long long)fr * e.in_frame + sb * SAF_HOP;
         float* dst = e.hist_wr + ((long long)inst * e.nCh + ch) * SAF_ANA_HIST * SAF_HOP + fn;
+        const int hq = H - SAF_ANA_HIST + (lane & 15);
+        const unsigned offH = hop_off_bytes(hq < 0 ? 0 : hq);
 #pragma unroll
         for (int row = 0; row < SAF_ANA_HIST; row++) {
             const int h = H - SAF_ANA_HIST + row;
-            const float v = h < 0 ? hist[(SAF_ANA_HIST + h) * SAF_HOP] : ld_in(inBase + off) * scale;
-            dst[row * SAF_HOP] = v;
-            if (h >= 0) { sb++; off += SAF_HOP; if (sb == T) { sb = 0; off += e.in_frame - (long long)T * SAF_HOP; } }
+            dst[row * SAF_HOP] = h < 0 ? hist[(SAF_ANA_HIST + h) * SAF_HOP] : ld_at(__builtin_amdgcn_readlane(offH, row)) * scale;
         }
     }
+#ifdef EQ_STAMPS
+    if (stampOn && lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g.stamps[wv * 12 + i], stampAcc[i]);
+#endif
     if (e.syn_wr && last) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
@@ -377,17 +413,30 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     }
 }
 
+static unsigned long long* g_eq_stamps = nullptr;
+static unsigned long long* eq_stamps_buffer()
+{
+#ifdef EQ_STAMPS
+    if (!g_eq_stamps) { HIP_CHECK(hipMalloc((void**)&g_eq_stamps, 24 * sizeof(unsigned long long))); HIP_CHECK(hipMemset(g_eq_stamps, 0, 24 * sizeof(unsigned long long))); }
+#endif
+    return g_eq_stamps;
+}
+
 void launch_eq(const EqLaunch& e)
 {
     if (e.H <= 0 || e.nCh <= 0 || e.nInst <= 0) return;
     if (e.D != 1 && e.D != 2) SAF_FATAL("filterbank equaliser: D must be 1 or 2");
-    if ((unsigned long long)(e.nChIn > 0 ? e.nChIn : 1) * (unsigned long long)(e.in_ch < 0 ? -e.in_ch : e.in_ch) * 4ull >= (1ull << 32))
-        SAF_FATAL("filterbank equaliser: one instance's channel block exceeds 4 GiB (split the call)");
+    /* the kernel addresses one instance's samples with 32-bit byte offsets (channel offset + hop offset) from a uniform base */
+    const long long chSpan = (long long)(e.nChIn > 0 ? e.nChIn : 1) * e.in_ch;
+    const long long hopSpan = (long long)((e.H + e.hopsPerFrame - 1) / e.hopsPerFrame) * e.in_frame + (long long)e.hopsPerFrame * SAF_HOP;
+    if (e.in_ch < 0 || e.in_frame < 0 || e.H >= (1 << 22) || (chSpan + hopSpan) * 4 >= (1ll << 32))
+        SAF_FATAL("filterbank equaliser: one call spans more than 4 GiB of one instance's input, 2^22 hops or uses negative strides: split the call");
     EqArgs g;
     g.e = e;
     g.win = dev_window(0, 0);
     g.twJ = dev_twiddles();
     g.tw256 = g.twJ + 128;
+    g.stamps = eq_stamps_buffer();
     /* time chunks only when the (channel, instance) grid leaves most of the chip idle: every extra chunk processes 16 more hops.
      * Aim at ~1024 workgroups with chunks of >= 64 hops (multiples of 16). */
     g.chunk = e.H;
@@ -405,3 +454,11 @@ void launch_eq(const EqLaunch& e)
 }
 
 }  // namespace saf
+
+#ifdef EQ_STAMPS
+extern "C" __attribute__((visibility("default"))) void saf_hip_debug_eq_stamps(unsigned long long* out16)
+{
+    HIP_CHECK(hipStreamSynchronize(saf::stream()));
+    if (saf::g_eq_stamps) { HIP_CHECK(hipMemcpy(out16, saf::g_eq_stamps, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost)); HIP_CHECK(hipMemset(saf::g_eq_stamps, 0, 24 * sizeof(unsigned long long))); }
+}
+#endif
