@@ -198,6 +198,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
             if (k & 1) fo = fmaf(xv, w[k], fo); else fe = fmaf(xv, w[k], fe);
         }
         float* slot = s_ring + t * SLOT;
+        if (D == 1 && uni) { fe *= sc[0]; fo *= sc[0]; }      /* uniform channel: the folds of hops -3 .. -1 are the frames of output hops 0 .. 2 */
         slot[fn] = fe; slot[128 + fn] = fo;
     }
     lds_barrier();
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
                 for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
                 const int pos = pN + t >= ERING ? pN + t - ERING : pN + t;
                 float* slot = s_ring + pos * SLOT;
+                if (D == 1 && uni) { fe *= sc[0]; fo *= sc[0]; }      /* uniform channel: the fold IS the frame; its gain goes in here */
                 slot[fn] = fe; slot[128 + fn] = fo;
             }
         }
@@ -363,7 +365,8 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
                         if (u < nh) {
                             const int uu = half * EQ_OLA + u;
                             const float* slot = (d == 0 || uni) ? lag_slot(uu) : s_out1 + uu * SLOT;
-                            gl[d][9 + u] = slot[tid] * sc[d]; gr[d][9 + u] = slot[128 + tid] * sc[d];
+                            if (D == 1) { gl[d][9 + u] = slot[tid]; gr[d][9 + u] = slot[128 + tid]; }
+                            else { gl[d][9 + u] = slot[tid] * sc[d]; gr[d][9 + u] = slot[128 + tid] * sc[d]; }
                             float acc = 0.0f;
 #pragma unroll
                             for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
