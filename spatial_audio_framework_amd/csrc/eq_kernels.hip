@@ -370,7 +370,11 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
                             float acc = 0.0f;
 #pragma unroll
                             for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
-                            if (emit) (zBase[d] + (long long)(s0 + uu) * SAF_HOP)[tid] = acc;
+                            if (emit) {      /* uniform 64-bit base (scalar registers) + 4 * tid */
+                                const unsigned long long zb = (unsigned long long)(zBase[d] + (long long)(s0 + uu) * SAF_HOP);
+                                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)zb), hi = __builtin_amdgcn_readfirstlane((unsigned)(zb >> 32));
+                                *reinterpret_cast<float*>(reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo) + (unsigned)(tid * 4)) = acc;
+                            }
                         }
                     }
                     if (nh == EQ_OLA) {
