@@ -158,9 +158,13 @@ def run_rank(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
 
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if (world > 1 and not args.share_gpu) else 0)
     torch.cuda.set_device(dev)
-    P.init(backend="nccl", device=dev)          # RCCL; ranks only meet in the barriers and the MAX of the elapsed time
+    if args.share_gpu:
+        P.init(backend="gloo")                  # rehearsal: N ranks on one GPU
+    else:
+        P.init(backend="nccl", device=dev)      # RCCL; ranks only meet in the barriers and the MAX of the elapsed time
+    rdev = "cpu" if args.share_gpu else dev     # where the timing reduction lives
 
     from spatial_audio_framework_amd import api
     from spatial_audio_framework_amd._lib import load
@@ -202,7 +206,7 @@ def run_rank(args):
         dt = time.perf_counter() - t0
         region_events_ms.setdefault(mode, ev_ms)        # the headline region runs first
         L.saf_hip_profile_enable(0)
-        dt = P.max_over_ranks(dt, device=dev)
+        dt = P.max_over_ranks(dt, device=rdev)
         per = {}
         for k in kernels:
             tot = C.c_double()
@@ -336,6 +340,7 @@ def main():
     ap.add_argument("--no-extra-paths", action="store_true", help="only the headline timed region (used by the PMC passes)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short regions of the other BASELINE configs")
     ap.add_argument("--path-mode", type=int, default=2, help="block path of the headline region (saf_hip_ambi_dec_setTimeDomainPath); profiling passes use 0 / 1")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a one-GPU box: every rank uses cuda:0 and the ranks meet over gloo (RCCL needs one device per rank)")
     ap.add_argument("--dry-run", action="store_true", help="exercise launch / rendezvous / reduction with gloo, no GPU work (CPU tests)")
     ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--pin-core", type=int, default=None, help=argparse.SUPPRESS)

@@ -101,3 +101,18 @@ def build_oracle(orc):
     d.setNormType(1); d.setChOrder(1); d.setMasterDecOrder(S.ORDER); d.setOutputConfigPreset(29)
     d.setDecMethod(0, 1); d.setDecMethod(1, 1); d.initCodec(); d.init(48000); d.setDecOrderAllBands(S.ORDER)
     return encs, d
+
+
+def test_bench_spawns_two_ranks_on_the_gpu_box():
+    """`python bench.py --gpus 2` starts two ranks itself; on this one-GPU box they share cuda:0 and meet over gloo
+    (--share-gpu): every rank builds its own pipelines, runs the timed steps between the barriers, rank 0 reports the MAX."""
+    import json, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in __import__("os").environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1", "--instances", "8",
+                        "--frames-per-call", "8", "--no-cpu-baseline", "--no-extra-paths"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["instances_per_gpu"] == 8
+    assert line["roofline"]["kernels_ms"]["afstft_eq"] > 0
