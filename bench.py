@@ -256,7 +256,7 @@ def run_rank(args):
     value = frames_total / elapsed
 
     other = None
-    if rank == 0 and not args.no_other_configs and not args.no_extra_paths:
+    if world == 1 and not args.no_other_configs and not args.no_extra_paths:      # single-GPU information: not part of a scaling run
         del xs, y
         torch.cuda.empty_cache()
         sys.path.insert(0, str(ROOT / "tools"))
