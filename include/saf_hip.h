@@ -61,10 +61,9 @@ typedef enum {                      /* afSTFTlib.h:79-83 */
     AFSTFT_TIME_CH_BANDS
 } AFSTFT_FDDATA_FORMAT;
 
-/** afSTFTlib.h:107 / afSTFTlib.c:142.  hopsize must be 128: the reference also accepts 64 and 256 (afSTFTlib.c:158-159),
- *  but every operator of the path fixes HOP_SIZE at 128 (e.g. ambi_dec_internal.h:68, binauraliser_internal.h:63,
- *  powermap_internal.h:67) and the kernels are specialised for it (1280-tap window, 256-point transform as 8 lanes x 16
- *  points, 133 hybrid bands); another hop size aborts with a message instead of running an untested path. */
+/** afSTFTlib.h:107 / afSTFTlib.c:142.  hopsize 64, 128 or 256 (what the reference accepts in hybrid mode, afSTFTlib.c:158-159).
+ *  128 — the value every operator of the path fixes (ambi_dec_internal.h:68, binauraliser_internal.h:63, powermap_internal.h:67)
+ *  — runs the tuned kernels; 64 and 256 run generic, untuned kernels (csrc/afstft_generic.hip) of the same algorithm. */
 SAF_API void afSTFT_create(void** const phSTFT, int nCHin, int nCHout, int hopsize, int lowDelayMode, int hybridmode, AFSTFT_FDDATA_FORMAT format);
 SAF_API void afSTFT_destroy(void** const phSTFT);                                                         /* afSTFTlib.h:120 */
 /** afSTFTlib.h:85 / afSTFTlib.c:78-119: one-shot analysis with a fresh filterbank; inTD [nSamplesTD][nCH], outTF [nBands][ceil(nSamplesTD/hop)][nCH]. */

@@ -13,12 +13,12 @@
 
 namespace saf {
 
-void AfState::create(int nInst_, int nIn, int nOut)
+void AfState::create(int nInst_, int nIn, int nOut, int hop_)
 {
-    nInst = nInst_; nCHin = nIn; nCHout = nOut;
+    nInst = nInst_; nCHin = nIn; nCHout = nOut; hop = hop_;
     for (int i = 0; i < 2; i++) {
-        ana[i].alloc((size_t)nInst * (nIn > 0 ? nIn : 1) * SAF_ANA_HIST * SAF_HOP);
-        syn[i].alloc((size_t)nInst * (nOut > 0 ? nOut : 1) * SAF_SYN_HIST * 256);
+        ana[i].alloc((size_t)nInst * (nIn > 0 ? nIn : 1) * SAF_ANA_HIST * hop);
+        syn[i].alloc((size_t)nInst * (nOut > 0 ? nOut : 1) * SAF_SYN_HIST * 2 * hop);
     }
     anaPar = synPar = 0;
 }
@@ -34,11 +34,11 @@ void AfState::channelChange(int newIn, int newOut)
     if (nInst != 1) SAF_FATAL("channelChange on a batched state is not supported");
     if (newIn != nCHin) {
         DevBuf<float> n0, n1;
-        n0.alloc((size_t)(newIn > 0 ? newIn : 1) * SAF_ANA_HIST * SAF_HOP);
-        n1.alloc((size_t)(newIn > 0 ? newIn : 1) * SAF_ANA_HIST * SAF_HOP);
+        n0.alloc((size_t)(newIn > 0 ? newIn : 1) * SAF_ANA_HIST * hop);
+        n1.alloc((size_t)(newIn > 0 ? newIn : 1) * SAF_ANA_HIST * hop);
         const int keep = newIn < nCHin ? newIn : nCHin;
         if (keep > 0)
-            HIP_CHECK(hipMemcpyAsync(n0.p, ana[anaPar].p, (size_t)keep * SAF_ANA_HIST * SAF_HOP * sizeof(float), hipMemcpyDeviceToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(n0.p, ana[anaPar].p, (size_t)keep * SAF_ANA_HIST * hop * sizeof(float), hipMemcpyDeviceToDevice, stream()));
         HIP_CHECK(hipStreamSynchronize(stream()));
         std::swap(ana[0].p, n0.p); std::swap(ana[0].n, n0.n);
         std::swap(ana[1].p, n1.p); std::swap(ana[1].n, n1.n);
@@ -47,11 +47,11 @@ void AfState::channelChange(int newIn, int newOut)
     }
     if (newOut != nCHout) {
         DevBuf<float> n0, n1;
-        n0.alloc((size_t)(newOut > 0 ? newOut : 1) * SAF_SYN_HIST * 256);
-        n1.alloc((size_t)(newOut > 0 ? newOut : 1) * SAF_SYN_HIST * 256);
+        n0.alloc((size_t)(newOut > 0 ? newOut : 1) * SAF_SYN_HIST * 2 * hop);
+        n1.alloc((size_t)(newOut > 0 ? newOut : 1) * SAF_SYN_HIST * 2 * hop);
         const int keep = newOut < nCHout ? newOut : nCHout;
         if (keep > 0)
-            HIP_CHECK(hipMemcpyAsync(n0.p, syn[synPar].p, (size_t)keep * SAF_SYN_HIST * 256 * sizeof(float), hipMemcpyDeviceToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(n0.p, syn[synPar].p, (size_t)keep * SAF_SYN_HIST * 2 * hop * sizeof(float), hipMemcpyDeviceToDevice, stream()));
         HIP_CHECK(hipStreamSynchronize(stream()));
         std::swap(syn[0].p, n0.p); std::swap(syn[0].n, n0.n);
         std::swap(syn[1].p, n1.p); std::swap(syn[1].n, n1.n);
@@ -83,7 +83,7 @@ static void run_forward(AfSTFT* h, const float* d_td, long long td_ch, int nHops
     a.hist_rd = h->st.ana[h->st.anaPar].p; a.hist_wr = h->st.ana[h->st.anaPar ^ 1].p;
     a.out = d_fd; a.out_inst = 0; a.out_band = fd_band; a.out_ch = fd_ch;
     a.ch_scale = nullptr; a.ch_map = nullptr;
-    a.nCh = h->st.nCHin; a.nInst = 1; a.H = nHops; a.lowDelay = h->lowDelay; a.hybrid = h->hybrid;
+    a.nCh = h->st.nCHin; a.nInst = 1; a.H = nHops; a.lowDelay = h->lowDelay; a.hybrid = h->hybrid; a.hop = h->hop;
     launch_analysis(a);
     h->st.anaPar ^= 1;
 }
@@ -95,7 +95,7 @@ static void run_backward(AfSTFT* h, const float2* d_fd, long long fd_band, long 
     s.in = d_fd; s.in_inst = 0; s.in_band = fd_band; s.in_ch = fd_ch;
     s.out = d_td; s.out_inst = 0; s.out_ch = td_ch; s.out_frame = 0; s.hopsPerFrame = nHops;
     s.hist_rd = h->st.syn[h->st.synPar].p; s.hist_wr = h->st.syn[h->st.synPar ^ 1].p;
-    s.nCh = h->st.nCHout; s.nInst = 1; s.H = nHops; s.lowDelay = h->lowDelay; s.hybrid = h->hybrid;
+    s.nCh = h->st.nCHout; s.nInst = 1; s.H = nHops; s.lowDelay = h->lowDelay; s.hybrid = h->hybrid; s.hop = h->hop;
     launch_synthesis(s);
     h->st.synPar ^= 1;
 }
@@ -139,14 +139,15 @@ extern "C" {
 void afSTFT_create(void** const phSTFT, int nCHin, int nCHout, int hopsize, int lowDelayMode, int hybridmode, AFSTFT_FDDATA_FORMAT format)
 {
     ensure_device();
-    if (hopsize != SAF_HOP)
-        SAF_FATAL("afSTFT_create: hopsize %d is not implemented in this build (only 128, the value every SAF operator uses)", hopsize);
+    /* afSTFTlib.c:158-159: 64, 128 or 256 in hybrid mode.  128 runs the tuned kernels, 64 / 256 the generic ones. */
+    if (hopsize != 64 && hopsize != 128 && hopsize != 256)
+        SAF_FATAL("afSTFT_create: hopsize %d is not supported (64, 128 or 256)", hopsize);
     AfSTFT* h = new AfSTFT();
     h->hop = hopsize; h->lowDelay = lowDelayMode ? 1 : 0; h->hybrid = hybridmode ? 1 : 0; h->format = format;
     h->nBands = hybridmode ? hopsize + 5 : hopsize + 1;                       /* afSTFTlib.c:165 */
     if (lowDelayMode) h->delay = hybridmode ? 7 * hopsize : 4 * hopsize;      /* afSTFTlib.c:166-169 */
     else              h->delay = hybridmode ? 12 * hopsize : 9 * hopsize;
-    h->st.create(1, nCHin, nCHout);
+    h->st.create(1, nCHin, nCHout, hopsize);
     *phSTFT = h;
 }
 
@@ -349,7 +350,7 @@ void saf_hip_afSTFT_backward_dev(void* const hSTFT, const float_complex* d_fd, l
 void afSTFT_FIRtoFilterbankCoeffs(float* hIR, int N_dirs, int nCH, int ir_len, int hopSize, int LDmode, int hybridmode, float_complex* hFB)
 {
     ensure_device();
-    if (hopSize != SAF_HOP) SAF_FATAL("afSTFT_FIRtoFilterbankCoeffs: only hopSize 128 is implemented");
+    if (hopSize != 64 && hopSize != 128 && hopSize != 256) SAF_FATAL("afSTFT_FIRtoFilterbankCoeffs: hopSize %d is not supported (64, 128 or 256)", hopSize);
     const int nBands = hopSize + (hybridmode ? 5 : 1);
     const int ir_pad = 1024;
     const int maxlen = (ir_len > hopSize ? ir_len : hopSize) + ir_pad;
@@ -371,7 +372,7 @@ void afSTFT_FIRtoFilterbankCoeffs(float* hIR, int N_dirs, int nCH, int ir_len, i
     for (int nd = 0; nd < N_dirs; nd++)
         for (int c = 0; c < nCH; c++)
             memcpy(h_td.p + (size_t)(1 + nd * nCH + c) * L, hIR + ((size_t)nd * nCH + c) * ir_len, sizeof(float) * ir_len);
-    AfState st; st.create(1, nSig, 0);
+    AfState st; st.create(1, nSig, 0, hopSize);
     DevBuf<float> d_td; d_td.alloc((size_t)nSig * L, false);
     DevBuf<float2> d_fd; d_fd.alloc((size_t)nBands * nSig * nT, false);
     HIP_CHECK(hipMemcpyAsync(d_td.p, h_td.p, sizeof(float) * (size_t)nSig * L, hipMemcpyHostToDevice, stream()));
@@ -379,7 +380,7 @@ void afSTFT_FIRtoFilterbankCoeffs(float* hIR, int N_dirs, int nCH, int ir_len, i
     a.in = d_td.p; a.in_ch = L; a.hopsPerFrame = nT; a.nChIn = nSig;
     a.hist_rd = st.ana[0].p; a.hist_wr = nullptr;
     a.out = d_fd.p; a.out_band = (long long)nSig * nT; a.out_ch = nT;
-    a.nCh = nSig; a.nInst = 1; a.H = nT; a.lowDelay = LDmode ? 1 : 0; a.hybrid = hybridmode ? 1 : 0;
+    a.nCh = nSig; a.nInst = 1; a.H = nT; a.lowDelay = LDmode ? 1 : 0; a.hybrid = hybridmode ? 1 : 0; a.hop = hopSize;
     launch_analysis(a);
     std::vector<float2> fd((size_t)nBands * nSig * nT);
     HIP_CHECK(hipMemcpyAsync(fd.data(), d_fd.p, sizeof(float2) * fd.size(), hipMemcpyDeviceToHost, stream()));

@@ -601,6 +601,7 @@ const float2* dev_twiddles()
 void launch_analysis(const AnaLaunch& a)
 {
     if (a.H <= 0 || a.nCh <= 0 || a.nInst <= 0) return;
+    if (a.hop != SAF_HOP) { launch_analysis_generic(a); return; }
     AnaArgs g;
     g.a = a;
     g.win = dev_window(a.lowDelay, 0);
@@ -637,6 +638,7 @@ void launch_analysis(const AnaLaunch& a)
 void launch_synthesis(const SynLaunch& s)
 {
     if (s.H <= 0 || s.nCh <= 0 || s.nInst <= 0) return;
+    if (s.hop != SAF_HOP) { launch_synthesis_generic(s); return; }
     SynArgs g;
     g.s = s;
     g.win = dev_window(s.lowDelay, 1);

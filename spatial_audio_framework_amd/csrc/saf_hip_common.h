@@ -122,8 +122,10 @@ struct AnaLaunch {
     int tab_stride;             /* instance stride of ch_scale / ch_map (0: nCh) */
     int nCh, nInst, H;          /* H = hops in this launch */
     int lowDelay, hybrid;
+    int hop = SAF_HOP;          /* 128: the tuned kernels; 64 / 256: the generic ones (afstft_generic.hip), state sized by the hop */
 };
 void launch_analysis(const AnaLaunch& a);
+void launch_analysis_generic(const AnaLaunch& a);
 
 struct SynLaunch {
     const float2* in;           /* spectra in[inst*in_inst + band*in_band + ch*in_ch + hop] */
@@ -135,8 +137,10 @@ struct SynLaunch {
     float* hist_wr;
     int nCh, nInst, H;
     int lowDelay, hybrid;
+    int hop = SAF_HOP;
 };
 void launch_synthesis(const SynLaunch& s);
+void launch_synthesis_generic(const SynLaunch& s);
 
 /* ---- per-band dynamic range compression on the spectra (drc_kernels.hip; ambi_drc.c:168-199) ---- */
 struct DrcLaunch {

@@ -169,3 +169,40 @@ def test_operator_lifecycle_does_not_leak_device_memory(saf):
         "powermap": loop(pm, lambda p: [p.analysis(frames(3, 16, 1024)) for _ in range(2)], 6),
     }
     assert all(v > -8.0 for v in deltas.values()), deltas      # MiB; allocator granularity, not growth per cycle
+
+
+@pytest.mark.parametrize("hop", [64, 256])
+@pytest.mark.parametrize("hybrid,ld", [(1, 0), (0, 0), (1, 1), (0, 1)])
+def test_afSTFT_other_hop_sizes_vs_oracle(saf, orc, hop, hybrid, ld):
+    """hop sizes 64 and 256 (afSTFTlib.c:158-159 accepts them next to 128; no operator uses them): the generic kernels against
+    the oracle — forward spectra, backward samples, state carried over calls of different lengths, the round-trip property of
+    the reference's test__afSTFT (test__resources.c:27-100: output = input delayed by afSTFT_getProcDelay within 0.01)"""
+    nIn, nOut = 3, 2
+    g, o = saf.AfSTFT(nIn, nOut, hop, ld, hybrid), orc.AfSTFT(nIn, nOut, hop, ld, hybrid)
+    assert g.nBands == o.nBands == hop + (5 if hybrid else 1) and g.delay == o.delay
+    x = frames(77 + hop, nIn, 40 * hop)
+    pos, Xg, Xo = 0, [], []
+    for nh in (1, 7, 12, 20):                                      # calls of different lengths: the state carries over
+        blk = np.ascontiguousarray(x[:, pos * hop:(pos + nh) * hop]); pos += nh
+        Xg.append(g.forward(blk)); Xo.append(o.forward(blk))
+    Xg, Xo = np.concatenate(Xg, 2), np.concatenate(Xo, 2)
+    assert relrms(Xg, Xo) < 2e-6
+    Y = np.ascontiguousarray(Xo[:, :nOut, :])
+    yg, yo = [], []
+    pos = 0
+    for nh in (3, 9, 28):
+        yg.append(g.backward(np.ascontiguousarray(Y[:, :, pos:pos + nh]))); yo.append(o.backward(np.ascontiguousarray(Y[:, :, pos:pos + nh]))); pos += nh
+    yg, yo = np.concatenate(yg, 1), np.concatenate(yo, 1)
+    assert relrms(yg, yo) < 2e-6
+    d = g.delay
+    # near-perfect reconstruction: the reference's test asserts 0.01 in normal-delay mode (it does not test the low-delay mode,
+    # whose prototype filter reconstructs within ~0.012)
+    assert np.abs(yg[:, d:] - x[:nOut, :yg.shape[1] - d]).max() < (0.02 if ld else 0.01)
+
+
+def test_afSTFT_FIRtoFilterbankCoeffs_other_hop_sizes(saf, orc):
+    rng = np.random.default_rng(3)
+    ir = (rng.normal(size=(4, 2, 200)) * np.exp(-np.arange(200) / 30.0)).astype(np.float32)
+    for hop in (64, 256):
+        a, b = saf.afSTFT_FIRtoFilterbankCoeffs(ir, hop, 0, 1), orc.FIRtoFilterbankCoeffs(ir, hop, 0, 1)
+        assert a.shape == b.shape and relrms(a, b) < 1e-5
