@@ -448,112 +448,6 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
 }
 
 /* ========================================================================== */
-/*        analysis -> synthesis of one signal without the transforms          */
-/* ========================================================================== */
-
-struct RtArgs { RoundtripLaunch r; const float* winA; const float* winS; };
-
-/* thread = (channel, two sample positions); grid (ceil(nCh * 64 / 256), nInst).
- *   fold (afSTFT_internal.c:276-301):        f_t[(k&1) 128 + n] = sum_k x_{t-9+k}[n] wA[k 128 + n]
- *   FFT, hybrid split, merge, inverse FFT:   frame of output hop t = f_{t-3}          (the transforms cancel; 3-hop delay)
- *   overlap-add (afSTFT_internal.c:396-444): out_t[n] = sum_k wS[k 128 + n] frame_{t-k}[(k&1) 128 + n]
- * The 9 frames before the call come from the synthesis state, exactly as in the transform path, so the two paths can
- * alternate call by call. */
-#define RT_U 8
-/* thread = (channel, pair of sample positions 2m, 2m+1): 8-byte accesses, 512 contiguous bytes per wave and hop */
-__global__ __launch_bounds__(256) void afstft_roundtrip_kernel(RtArgs g)
-{
-    const RoundtripLaunch& r = g.r;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int ch = e >> 6, n = 2 * (e & 63), inst = blockIdx.y;
-    if (ch >= r.nCh) return;
-    float2 wa[10], ws[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) { wa[k] = *reinterpret_cast<const float2*>(g.winA + k * SAF_HOP + n); ws[k] = *reinterpret_cast<const float2*>(g.winS + k * SAF_HOP + n); }
-    /* x[i] = y hop (t0 - 12 + i): the fold of frame t-3 reads y hops t-12 .. t-3; y index 0 is hop t0 - 15 */
-    const float* y = r.y + (long long)inst * r.y_inst + (long long)ch * r.y_ch + n;
-    float2 x[9 + RT_U], gl[9 + RT_U], gr[9 + RT_U];
-#pragma unroll
-    for (int i = 0; i < 9; i++) x[i] = *reinterpret_cast<const float2*>(y + (3 + i) * SAF_HOP);
-    {
-        const float* h = r.syn_rd + ((long long)inst * r.nCh + ch) * SAF_SYN_HIST * 256;
-#pragma unroll
-        for (int i = 0; i < 9; i++) { gl[i] = *reinterpret_cast<const float2*>(h + i * 256 + n); gr[i] = *reinterpret_cast<const float2*>(h + i * 256 + 128 + n); }
-    }
-    float* outBase = r.out + (long long)inst * r.out_inst + (long long)ch * r.out_ch + n;
-    const int T = r.hopsPerFrame;
-    int oFrame = 0, oSub = 0;
-    for (int t0 = 0; t0 < r.H; t0 += RT_U) {
-        const int nh = min(RT_U, r.H - t0);
-#pragma unroll
-        for (int u = 0; u < RT_U; u++) {                             /* all loads first; hops beyond the call re-read the last one */
-            const int hh = t0 + (u < nh ? u : nh - 1);
-            x[9 + u] = *reinterpret_cast<const float2*>(y + (long long)(12 + hh) * SAF_HOP);
-        }
-#pragma unroll
-        for (int u = 0; u < RT_U; u++) {
-            if (u < nh) {
-                float2 fe = make_float2(0.f, 0.f), fo = fe;
-#pragma unroll
-                for (int i = 0; i < 5; i++) {
-                    fe.x = fmaf(x[u + 2 * i].x, wa[2 * i].x, fe.x); fe.y = fmaf(x[u + 2 * i].y, wa[2 * i].y, fe.y);
-                    fo.x = fmaf(x[u + 2 * i + 1].x, wa[2 * i + 1].x, fo.x); fo.y = fmaf(x[u + 2 * i + 1].y, wa[2 * i + 1].y, fo.y);
-                }
-                gl[9 + u] = fe; gr[9 + u] = fo;
-                float2 acc = make_float2(0.f, 0.f);
-#pragma unroll
-                for (int k = 9; k >= 0; k--) {
-                    const float2 v = (k & 1) ? gr[9 + u - k] : gl[9 + u - k];
-                    acc.x = fmaf(ws[k].x, v.x, acc.x); acc.y = fmaf(ws[k].y, v.y, acc.y);
-                }
-                *reinterpret_cast<float2*>(outBase + (long long)oFrame * r.out_frame + oSub * SAF_HOP) = acc;
-                oSub++; if (oSub == T) { oSub = 0; oFrame++; }
-            }
-        }
-        if (nh == RT_U) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) { x[i] = x[i + RT_U]; gl[i] = gl[i + RT_U]; gr[i] = gr[i + RT_U]; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                float2 a = gl[i], b = gr[i];
-#pragma unroll
-                for (int q = 1; q < RT_U; q++) if (q == nh) { a = gl[i + q]; b = gr[i + q]; }
-                gl[i] = a; gr[i] = b;
-            }
-        }
-    }
-    if (r.syn_wr) {
-        float* h = r.syn_wr + ((long long)inst * r.nCh + ch) * SAF_SYN_HIST * 256;
-#pragma unroll
-        for (int i = 0; i < 9; i++) { *reinterpret_cast<float2*>(h + i * 256 + n) = gl[i]; *reinterpret_cast<float2*>(h + i * 256 + 128 + n) = gr[i]; }
-    }
-}
-
-struct AhArgs { AnaHistLaunch a; };
-/* grid (nCh, nInst), 15 x 32 threads: hist_wr[ch][row] = hop (H - 15 + row) of [old history | converted input]; 16-byte accesses */
-__global__ __launch_bounds__(SAF_ANA_HIST * 32) void ana_hist_update_kernel(AhArgs g)
-{
-    const AnaHistLaunch& a = g.a;
-    const int ch = blockIdx.x, inst = blockIdx.y;
-    const int row = threadIdx.x >> 5, n = 4 * (threadIdx.x & 31);
-    const int tabStride = a.tab_stride ? a.tab_stride : a.nCh;
-    const int h = a.H - SAF_ANA_HIST + row;
-    float4 v;
-    if (h < 0) v = *reinterpret_cast<const float4*>(a.hist_rd + ((long long)inst * a.nCh + ch) * (SAF_ANA_HIST * SAF_HOP) + (SAF_ANA_HIST + h) * SAF_HOP + n);
-    else {
-        const int src = a.ch_map ? a.ch_map[inst * tabStride + ch] : ch;
-        const bool valid = src >= 0 && src < a.nChIn;
-        const float sc = valid ? (a.ch_scale ? a.ch_scale[inst * tabStride + ch] : 1.0f) : 0.0f;
-        const int fr = h / a.hopsPerFrame, sb = h - fr * a.hopsPerFrame;
-        const float* p = a.in + (long long)inst * a.in_inst + (long long)fr * a.in_frame + (long long)(valid ? src : 0) * a.in_ch + sb * SAF_HOP + n;
-        v = a.vec4 ? *reinterpret_cast<const float4*>(p) : make_float4(p[0], p[1], p[2], p[3]);
-        v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-    }
-    *reinterpret_cast<float4*>(a.hist_wr + ((long long)inst * a.nCh + ch) * (SAF_ANA_HIST * SAF_HOP) + row * SAF_HOP + n) = v;
-}
-
-/* ========================================================================== */
 /*                        constant tables + launchers                         */
 /* ========================================================================== */
 
@@ -658,25 +552,6 @@ void launch_synthesis(const SynLaunch& s)
     dim3 grid(s.nCh, s.nInst, (s.H + g.chunk - 1) / g.chunk);
     KernelTimer kt("afstft_synthesis");
     hipLaunchKernelGGL(afstft_synthesis_ws_kernel, grid, dim3(256), 0, stream(), g);
-    HIP_CHECK(hipGetLastError());
-}
-
-void launch_roundtrip(const RoundtripLaunch& r)
-{
-    if (r.H <= 0 || r.nCh <= 0 || r.nInst <= 0) return;
-    RtArgs g; g.r = r; g.winA = dev_window(0, 0); g.winS = dev_window(0, 1);
-    KernelTimer kt("afstft_roundtrip");
-    if ((r.out_inst | r.out_ch | r.out_frame) & 1 || (((uintptr_t)r.out) & 7)) SAF_FATAL("afSTFT round trip: output strides must be even and the base 8-byte aligned");
-    hipLaunchKernelGGL(afstft_roundtrip_kernel, dim3((r.nCh * 64 + 255) / 256, r.nInst), dim3(256), 0, stream(), g);
-    HIP_CHECK(hipGetLastError());
-}
-
-void launch_ana_hist_update(const AnaHistLaunch& a)
-{
-    if (a.nCh <= 0 || a.nInst <= 0 || !a.hist_wr) return;
-    AhArgs g; g.a = a;
-    g.a.vec4 = ((a.in_inst | a.in_ch | a.in_frame) & 3) == 0 && (((uintptr_t)a.in) & 15) == 0;
-    hipLaunchKernelGGL(ana_hist_update_kernel, dim3(a.nCh, a.nInst), dim3(SAF_ANA_HIST * 32), 0, stream(), g);
     HIP_CHECK(hipGetLastError());
 }
 

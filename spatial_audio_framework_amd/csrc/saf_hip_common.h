@@ -152,27 +152,6 @@ struct DrcLaunch {
 };
 void launch_drc(const DrcLaunch& l);
 
-/* ---- afSTFT analysis -> synthesis of the SAME signal without the transforms (afstft_kernels.hip) ----
- * When nothing band-dependent happens between afSTFT_forward and afSTFT_backward, the 256-point FFT and its inverse
- * cancel and the hybrid split / merge reduces to its 3-hop delay: what remains is the window fold, a delay and the
- * 10-segment overlap-add — per sample position, no data exchange.  y holds, per (instance, channel), the 15 hops before
- * the call followed by the H hops of the call, contiguous in time. */
-struct RoundtripLaunch {
-    const float* y; long long y_inst, y_ch;            /* y[inst*y_inst + ch*y_ch + hop*128 + n], hop 0 = 15 hops before the call */
-    float* out; long long out_inst, out_ch, out_frame; int hopsPerFrame;
-    const float* syn_rd; float* syn_wr;                /* [inst][nCh][9][256] the synthesis state of AfState */
-    int nCh, nInst, H;
-};
-void launch_roundtrip(const RoundtripLaunch& r);
-/* new analysis history (last 15 hops of the converted input) without running the analysis: AfState::ana format */
-struct AnaHistLaunch {
-    const float* in; long long in_inst, in_ch, in_frame; int hopsPerFrame, nChIn;
-    const float* hist_rd; float* hist_wr; const float* ch_scale; const int* ch_map; int tab_stride;
-    int nCh, nInst, H;
-    bool vec4 = false;          /* set by the launcher: input strides / base allow 16-byte loads */
-};
-void launch_ana_hist_update(const AnaHistLaunch& a);
-
 /* ---- afSTFT analysis -> real gain per (channel, band) -> afSTFT synthesis in one kernel (eq_kernels.hip) ----
  * z_d[ch] = synthesis( gains[d][ch][band] (.) analysis(x[ch]) ) for d < D (1 or 2) and every channel; hybrid mode, normal
  * delay.  Input addressing, conventions (ch_map / ch_scale) and the input history are those of AnaLaunch; the frame
