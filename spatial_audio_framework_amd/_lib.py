@@ -5,11 +5,13 @@ any compute entry point fails loudly.
 """
 import ctypes as C
 import os
+import os
 import re
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-SO = PKG / "libsaf_hip.so"
+# SAF_HIP_LIB: another build of the same library (kernel A/B runs: tools/ab_variants.sh); the default is the in-tree build
+SO = Path(os.environ["SAF_HIP_LIB"]).resolve() if os.environ.get("SAF_HIP_LIB") else PKG / "libsaf_hip.so"
 HEADER = PKG.parent / "include" / "saf_hip.h"
 _lib = None
 

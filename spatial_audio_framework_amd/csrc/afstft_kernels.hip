@@ -42,16 +42,28 @@ namespace saf {
 /*                                 analysis                                   */
 /* ========================================================================== */
 
+#ifdef ANA_STAMPS
+static unsigned long long* g_ana_stamps = nullptr;
+#endif
 struct AnaArgs {
     AnaLaunch a;
     const float* win;      /* [1280] */
     const float2* twJ;     /* [8][16]  exp(-2 pi i j p / 128) */
     const float2* tw256;   /* [129]    exp(-2 pi i k / 256) */
     int chunk;
+    unsigned long long* stamps;
 };
+#ifdef ANA_STAMPS        /* diagnostic build only: cycles per phase of every 64th workgroup (tools/ana_stamps.py) */
+#define ASTAMP(i) do { if (stampOn && (tid & 63) == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += t_ - stampT; stampT = t_; } } while (0)
+#else
+#define ASTAMP(i) do { } while (0)
+#endif
 
 /* NCH = channels per workgroup (128 threads each).  NCH = 1 gives twice as many, half as large workgroups: more
  * independent fold / FFT / store pipelines per CU to overlap with each other. */
+#ifndef ANA_BATCH
+#define ANA_BATCH 4        /* regular items whose LDS reads are in flight together (split phase) */
+#endif
 template <int NCH>
 __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g)
 {
@@ -62,6 +74,10 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
     const int tid = threadIdx.x;
     const int inst = blockIdx.z;
     const int chBase = blockIdx.y * NCH;
+#ifdef ANA_STAMPS
+    const bool stampOn = g.stamps != nullptr && ((blockIdx.z * gridDim.y + blockIdx.y) & 63) == 0;
+    unsigned long long stampAcc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, stampT = __builtin_amdgcn_s_memtime();
+#endif
     const int c0 = blockIdx.x * g.chunk;
     const int c1 = min(c0 + g.chunk, g.a.H);
     if (c0 >= c1) return;
@@ -94,6 +110,14 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
         return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo) + offInB);
     };
+    const float invT = 1.0f / (float)T;
+    const int inFrame = (int)g.a.in_frame;
+    const char* inBaseB;                                    /* uniform: pinned to scalar registers */
+    {
+        const unsigned long long b = (unsigned long long)inBase;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        inBaseB = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
+    }
     float w[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) w[k] = g.win[k * SAF_HOP + fn];
@@ -146,13 +170,17 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
     /* (the barrier after the first fold below orders these spectra before their first use) */
 
     float2* outBase = g.a.out + (long long)inst * g.a.out_inst + (long long)chBase * g.a.out_ch;
-    const unsigned ob32 = (unsigned)g.a.out_band, oc32 = (unsigned)g.a.out_ch;
+    const unsigned ob32 = (unsigned)g.a.out_band;
     const int st = tid & 15, sr = tid >> 4;                /* store role: hop of the sub-chunk, item lane */
-    const int nC = g.a.nCh - chBase >= NCH ? NCH : g.a.nCh - chBase;
 
     int p0 = 6;                                            /* ring position of the sub-chunk's first hop */
+    ASTAMP(7);
     for (int s0 = c0; s0 < c1; s0 += SUB) {
         const int n = min(SUB, c1 - s0);                   /* hops of this sub-chunk */
+        if (s0 > c0) {                                     /* the hops requested in the previous iteration */
+#pragma unroll
+            for (int i = 0; i < SUB; i++) xin[9 + i] *= scale;
+        }
         /* 1. window + fold (afSTFT_internal.c:276-301): f[(k&1)*128 + n] = sum_k x[hop-9+k][n] * w[k*128+n] */
 #pragma unroll
         for (int t = 0; t < SUB; t++) {
@@ -172,13 +200,12 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
 #pragma unroll
             for (int row = 0; row < SAF_ANA_HIST; row++) dst[row * SAF_HOP] = xin[SUB + 9 - SAF_ANA_HIST + row];
         }
-        /* slide the window and prefetch the next sub-chunk's input while the FFT phase runs.  The loads land in xl[] and
-         * are consumed (scaled into the window) BEFORE the store phase: vmcnt retires in order, so a wait placed after
-         * the store phase would also wait for every spectrum store on its way to HBM. */
+        /* slide the window */
 #pragma unroll
         for (int i = 0; i < 9; i++) xin[i] = xin[i + SUB];
-        float xl[SUB];
         const bool more = s0 + SUB < c1;
+#ifdef ANA_PF_EARLY
+        float xl[SUB];
         if (more) {
 #pragma unroll
             for (int i = 0; i < SUB; i++) {
@@ -186,80 +213,139 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
                 if (s0 + SUB + i + 1 < c1) { curSub++; curOff += SAF_HOP; if (curSub == T) { curSub = 0; curOff += g.a.in_frame - (long long)T * SAF_HOP; } }
             }
         }
+#endif
+        ASTAMP(0);
         lds_barrier();
+        ASTAMP(1);
         /* 2. 256-point real FFT as a 128-point complex FFT of z[m] = f[2m] + i f[2m+1], in place in the slot */
         if (fftT < n) {
             int pos = p0 + fftT; if (pos >= ARING) pos -= ARING;
             fft128_slot<false>(s_ring + (fftC * ARING + pos) * SLOT, fj, twJ, SLOT_SG(pos));
         }
+        ASTAMP(2);
         lds_barrier();
+        ASTAMP(3);
+        /* The next sub-chunk's input is requested HERE, into the dead upper part of the window, and first used (scaled) by the
+         * next fold: in flight under the split phase.  The spectrum stores below are younger than these loads, so the fold's
+         * wait for them (vmcnt retires in order) does not wait for the stores; and no prefetch register is live across the FFT. */
+#ifdef ANA_PF_EARLY
         if (more) {
 #pragma unroll
-            for (int i = 0; i < SUB; i++) xin[9 + i] = xl[i] * scale;
+            for (int i = 0; i < SUB; i++) xin[9 + i] = xl[i];
         }
+#else
+        if (more) {
+            /* hop h starts at float index (h / T) * in_frame + (h % T) * 128: the offsets of the 16 hops are computed by 16 lanes at
+             * once (float reciprocal, exact for h < 2^22: launch_analysis checks) and handed out with v_readlane — a scalar cursor
+             * with its wrap test per hop is ~20 scalar instructions and two branches per load, here on the critical path */
+            const int hq = min(s0 + SUB + (tid & 15), c1 - 1);
+            const int fq = (int)(((float)hq + 0.5f) * invT);
+            const unsigned offN = (unsigned)(fq * inFrame + (hq - fq * T) * SAF_HOP) * 4u;
+#pragma unroll
+            for (int i = 0; i < SUB; i++) xin[9 + i] = *reinterpret_cast<const float*>(inBaseB + (__builtin_amdgcn_readlane(offN, i) + offInB));
+        }
+#endif
+        ASTAMP(4);
         /* 3. real-FFT split (bins k and 128-k share their inputs), hybrid split + 3-hop delay
-         *    (afSTFT_internal.c:523-623), stored time-contiguous: 16 lanes = 16 hops = one 128-byte row segment */
-        if (st < n) {
-            int pos = p0 + st; if (pos >= ARING) pos -= ARING;                 /* ring position of S_hop */
+         *    (afSTFT_internal.c:523-623), stored time-contiguous: 16 lanes = 16 hops = one 128-byte row segment.
+         *    Regular items (every thread, branch-free): (hop st, bins k and 128-k) for k = 0, 5..64 — k = 5 + sr + 8 ii, the last
+         *    round takes 61..63, 0 and 64 (k = 64 is its own partner: both of its stores write the same value to the same place).
+         *    Hybrid items (lanes 0..31 of each wave: hop st, bin b = 1 + 2 wv + (lane >> 4)): the two half-bands of bin b from the
+         *    spectra of hops t, t-2, t-4, t-6 and the bin itself 3 hops back (afSTFT_internal.c:595-619), and band 132 - b.
+         *    Straight-line code with the LDS reads of many items in flight at once: as a chain of read -> wait -> store per item
+         *    this phase was 46 % of the kernel. */
+        static_assert(NCH == 1, "the item schedule below assumes 8 item lanes per channel (128 threads)");
+        {
+            const int stc = st < n ? st : 0;                                   /* hops beyond the end shadow hop 0 (not stored) */
+            int pos = p0 + stc; if (pos >= ARING) pos -= ARING;                /* ring position of S_hop */
             int pD = pos - 3; if (pD < 0) pD += ARING;                         /* all bands are delayed 3 hops */
             if (!g.a.hybrid) pD = pos;                                         /* plain STFT bins, no hybrid delay */
-            const unsigned ohop = (unsigned)(s0 + st);
-            /* one item = bins k and 128-k of (channel c, this hop).  FIRST: k < 8, the only items that can hold the hybrid
-             * bins 1..4; LAST: k = 64, whose partner is itself.  The item loop is fully unrolled with these cases resolved
-             * at compile time: the kernel is instruction-issue bound, and the rolled loop with its exit test and per-item
-             * case analysis cost 9 % of its time. */
-            static_assert(NCH == 1, "the item schedule below assumes 8 item lanes per channel (128 threads)");
+            const bool stOn = st < n;
+            const float* slotD = s_ring + pD * SLOT;
+            const int sgD = SLOT_SG(pD);
             /* spectra stores: uniform 64-bit base + 32-bit byte offset per lane (launch_analysis checks that an instance's
              * spectra span less than 4 GiB): no 64-bit address arithmetic per store */
             char* const ob = reinterpret_cast<char*>(outBase);
-            auto put = [&](unsigned idx, float2 v) { *reinterpret_cast<float2*>(ob + (idx << 3)) = v; };
-            auto item = [&](int k, int c, bool FIRST, bool LAST) {
-                const float* ring = s_ring + c * ARING * SLOT;
-                const float2 W = s_tw256[k];
+            const unsigned ohop8 = (unsigned)(s0 + stc) << 3, ob8 = ob32 << 3;
+#ifdef ANA_NOSTORE   /* experiment: everything but the spectrum stores */
+            auto put = [&](unsigned off8, float2 v, bool on) { if (on && v.x == 1.2345e-30f) *reinterpret_cast<float2*>(ob + off8) = v; };
+#else
+            auto put = [&](unsigned off8, float2 v, bool on) { if (on) *reinterpret_cast<float2*>(ob + off8) = v; };
+#endif
+            const int hyb = g.a.hybrid;
+            /* all LDS reads of the eight regular items first (one wait), then the arithmetic and the stores */
+#pragma unroll
+            for (int bt = 0; bt < 8; bt += ANA_BATCH) {
+            float2 rZk[ANA_BATCH], rZm[ANA_BATCH], rW[ANA_BATCH];
+#pragma unroll
+            for (int i4 = 0; i4 < ANA_BATCH; i4++) {
+                const int ii = bt + i4;
+                int k = 5 + sr + 8 * ii;
+                if (ii == 7) k = sr < 3 ? 61 + sr : (sr == 3 ? 0 : (sr == 4 ? 64 : sr - 4));        /* sr 5..7: bins 1..3, stored by the plain STFT only */
+                rZk[i4] = *reinterpret_cast<const float2*>(slotD + 2 * (k ^ sgD));
+                rZm[i4] = *reinterpret_cast<const float2*>(slotD + 2 * (((128 - k) & 127) ^ sgD));
+                rW[i4] = s_tw256[k];
+            }
+#pragma unroll
+            for (int i4 = 0; i4 < ANA_BATCH; i4++) {
+                const int ii = bt + i4;
+                int k = 5 + sr + 8 * ii;
+                bool on = stOn;
+                if (ii == 7) { k = sr < 3 ? 61 + sr : (sr == 3 ? 0 : (sr == 4 ? 64 : sr - 4)); on = stOn && (sr < 5 || !hyb); }
+                const float2 Zk = rZk[i4], Zm = rZm[i4];
+                const float2 e = make_float2(Zk.x + Zm.x, Zk.y - Zm.y);
+                const float2 d = make_float2(Zk.x - Zm.x, Zk.y + Zm.y);
+                const float2 t = cmul(rW[i4], d);
+                const float2 Xk = make_float2(0.5f * (e.x + t.y), 0.5f * (e.y - t.x));
+                const float2 Xm = make_float2(0.5f * (e.x - t.y), 0.5f * (-e.y - t.x));
+                const unsigned bk = hyb ? (k == 0 ? 0u : (unsigned)(k + 4)) : (unsigned)k;
+                const unsigned bm = hyb ? (unsigned)(132 - k) : (unsigned)(128 - k);
+                put(bk * ob8 + ohop8, Xk, on);
+                put(bm * ob8 + ohop8, Xm, on);
+            }
+            }
+            /* hybrid items: ten LDS reads, then the arithmetic */
+            const int hbin = 1 + 2 * (tid >> 6) + ((tid >> 4) & 1);
+            float2 hS0, hS2, hS4, hS6, hXk, hXm;
+            if (hyb) {
+                int p2 = pos - 2; if (p2 < 0) p2 += ARING;
+                int p4 = pos - 4; if (p4 < 0) p4 += ARING;
+                int p6 = pos - 6; if (p6 < 0) p6 += ARING;
+                const float2 W = s_tw256[hbin];
+                hS0 = ana_bin_lo(s_ring + pos * SLOT, SLOT_SG(pos), hbin, W);
+                hS2 = ana_bin_lo(s_ring + p2 * SLOT, SLOT_SG(p2), hbin, W);
+                hS4 = ana_bin_lo(s_ring + p4 * SLOT, SLOT_SG(p4), hbin, W);
+                hS6 = ana_bin_lo(s_ring + p6 * SLOT, SLOT_SG(p6), hbin, W);
+                ana_bin_pair(slotD, sgD, hbin, W, hXk, hXm);
+            }
+            if (!hyb) {          /* plain STFT: bin 4 is left (bins 1..3 went with the last round) */
                 float2 Xk, Xm;
-                ana_bin_pair(ring + pD * SLOT, SLOT_SG(pD), k, W, Xk, Xm);
-                const unsigned o = (unsigned)c * oc32 + ohop;
-                if (!g.a.hybrid) {
-                    put((unsigned)k * ob32 + o, Xk);
-                    if (!LAST) put((unsigned)(128 - k) * ob32 + o, Xm);
-                    return;
-                }
-                if (!LAST) put((unsigned)(132 - k) * ob32 + o, Xm);                /* bins 5..128 -> bands 9..132 */
-                if (!FIRST || k == 0 || k >= 5) {
-                    put((unsigned)(k == 0 ? 0 : k + 4) * ob32 + o, Xk);
-                } else {
-                    int p2 = pos - 2; if (p2 < 0) p2 += ARING;
-                    int p4 = pos - 4; if (p4 < 0) p4 += ARING;
-                    int p6 = pos - 6; if (p6 < 0) p6 += ARING;
-                    const float2 S0 = ana_bin_lo(ring + pos * SLOT, SLOT_SG(pos), k, W);
-                    const float2 S2 = ana_bin_lo(ring + p2 * SLOT, SLOT_SG(p2), k, W);
-                    const float2 S4 = ana_bin_lo(ring + p4 * SLOT, SLOT_SG(p4), k, W);
-                    const float2 S6 = ana_bin_lo(ring + p6 * SLOT, SLOT_SG(p6), k, W);
-                    float gr, gi;
-                    gr = -COEFF1 * S0.y;          gi = COEFF1 * S0.x;
-                    gr -= COEFF2 * S2.y;          gi += COEFF2 * S2.x;
-                    gr += COEFF2 * S4.y;          gi -= COEFF2 * S4.x;
-                    gr += COEFF1 * S6.y;          gi -= COEFF1 * S6.x;
-                    const float dr = Xk.x * 0.5f, di = Xk.y * 0.5f;
-                    /* lower half-band (band 2k-1) of bins 1,3 subtracts, of bins 2,4 adds (afSTFT_internal.c:606-619) */
-                    const float sgn = (k & 1) ? -1.0f : 1.0f;
-                    put((unsigned)(2 * k - 1) * ob32 + o, make_float2(dr + sgn * gr, di + sgn * gi));
-                    put((unsigned)(2 * k) * ob32 + o, make_float2(dr - sgn * gr, di - sgn * gi));
-                }
-            };
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                if (c < nC) {
-                    item(sr, c, true, false);
-#pragma unroll
-                    for (int ii = 1; ii < 8; ii++) item(sr + 8 * ii, c, false, false);
-                    if (sr == 0) item(64, c, false, true);
-                }
+                ana_bin_pair(slotD, sgD, 4, s_tw256[4], Xk, Xm);
+                put(4u * ob8 + ohop8, Xk, stOn && sr == 0);
+                put(124u * ob8 + ohop8, Xm, stOn && sr == 0);
+            } else {
+                float gr, gi;
+                gr = -COEFF1 * hS0.y;          gi = COEFF1 * hS0.x;
+                gr -= COEFF2 * hS2.y;          gi += COEFF2 * hS2.x;
+                gr += COEFF2 * hS4.y;          gi -= COEFF2 * hS4.x;
+                gr += COEFF1 * hS6.y;          gi -= COEFF1 * hS6.x;
+                const float dr = hXk.x * 0.5f, di = hXk.y * 0.5f;
+                /* lower half-band (band 2b-1) of bins 1,3 subtracts, of bins 2,4 adds (afSTFT_internal.c:606-619) */
+                const float sgn = (hbin & 1) ? -1.0f : 1.0f;
+                const bool hOn = stOn && (tid & 32) == 0;
+                put((unsigned)(2 * hbin - 1) * ob8 + ohop8, make_float2(dr + sgn * gr, di + sgn * gi), hOn);
+                put((unsigned)(2 * hbin) * ob8 + ohop8, make_float2(dr - sgn * gr, di - sgn * gi), hOn);
+                put((unsigned)(132 - hbin) * ob8 + ohop8, hXm, hOn);
             }
         }
         p0 += n; if (p0 >= ARING) p0 -= ARING;
+        ASTAMP(5);
         lds_barrier();
+        ASTAMP(6);
     }
+#ifdef ANA_STAMPS
+    if (stampOn && (tid & 63) == 0) for (int i = 0; i < 8; i++) atomicAdd(&g.stamps[(tid >> 6) * 8 + i], stampAcc[i]);
+#endif
 
     /* the workgroup that owns the last chunk records the new input history: the last 15 input hops */
     if (c1 == g.a.H && (g.a.H % SUB) != 0 && g.a.hist_wr && fOn) {        /* partial last sub-chunk: reload */
@@ -519,7 +605,17 @@ void launch_analysis(const AnaLaunch& a)
         }
     }
     g.chunk = chunk;
+    g.stamps = nullptr;
+#ifdef ANA_STAMPS
+    { static unsigned long long* buf = nullptr; if (!buf) { HIP_CHECK(hipMalloc((void**)&buf, 16 * 8)); HIP_CHECK(hipMemset(buf, 0, 16 * 8)); } g.stamps = buf; g_ana_stamps = buf; }
+#endif
     /* the kernel addresses one instance's samples and spectra with 32-bit byte offsets from uniform bases */
+    {
+        const long long chSpan = (long long)(a.nChIn > 0 ? a.nChIn : 1) * a.in_ch;
+        const long long hopSpan = (long long)((a.H + a.hopsPerFrame - 1) / a.hopsPerFrame) * a.in_frame + (long long)a.hopsPerFrame * SAF_HOP;
+        if (a.in_ch < 0 || a.in_frame < 0 || a.H >= (1 << 22) || (chSpan + hopSpan) * 4 >= (1ll << 32))
+            SAF_FATAL("afSTFT analysis: one call spans more than 4 GiB of one instance's input, 2^22 hops or uses negative strides: split the call");
+    }
     if ((unsigned long long)(a.nChIn > 0 ? a.nChIn : 1) * (unsigned long long)(a.in_ch < 0 ? -a.in_ch : a.in_ch) * 4ull >= (1ull << 32) ||
         ((unsigned long long)SAF_NBANDS * (unsigned long long)a.out_band + (unsigned long long)a.nCh * (unsigned long long)a.out_ch + (unsigned long long)a.H) * 8ull >= (1ull << 32))
         SAF_FATAL("afSTFT analysis: one instance's channel block or spectra exceed 4 GiB (split the call)");
@@ -556,3 +652,11 @@ void launch_synthesis(const SynLaunch& s)
 }
 
 }  // namespace saf
+
+#ifdef ANA_STAMPS
+extern "C" __attribute__((visibility("default"))) void saf_hip_debug_ana_stamps(unsigned long long* out16)
+{
+    HIP_CHECK(hipStreamSynchronize(saf::stream()));
+    if (saf::g_ana_stamps) { HIP_CHECK(hipMemcpy(out16, saf::g_ana_stamps, 16 * 8, hipMemcpyDeviceToHost)); HIP_CHECK(hipMemset(saf::g_ana_stamps, 0, 16 * 8)); }
+}
+#endif
