@@ -183,16 +183,16 @@ __global__ __launch_bounds__(128 * NCH, 3) void afstft_analysis_kernel(AnaArgs g
         }
         /* 1. window + fold (afSTFT_internal.c:276-301): f[(k&1)*128 + n] = sum_k x[hop-9+k][n] * w[k*128+n] */
 #pragma unroll
+        /* (hops beyond the end of a partial last sub-chunk fold their clamped loads into slots nobody reads: sixteen folds of
+         * straight-line code) */
         for (int t = 0; t < SUB; t++) {
-            if (t < n) {
-                float fe = 0.0f, fo = 0.0f;
+            float fe = 0.0f, fo = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
-                int pos = p0 + t; if (pos >= ARING) pos -= ARING;
-                float* slot = s_ring + (fc * ARING + pos) * SLOT;
-                const int fa = 2 * ((fn >> 1) ^ SLOT_SG(pos)) + (fn & 1);
-                slot[fa] = fe; slot[128 + fa] = fo;
-            }
+            for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
+            int pos = p0 + t; if (pos >= ARING) pos -= ARING;
+            float* slot = s_ring + (fc * ARING + pos) * SLOT;
+            const int fa = 2 * ((fn >> 1) ^ SLOT_SG(pos)) + (fn & 1);
+            slot[fa] = fe; slot[128 + fa] = fo;
         }
         /* the workgroup that owns the end of the launch records the new input history (the last 15 hops) from its window */
         if (n == SUB && s0 + SUB == g.a.H && g.a.hist_wr && fOn) {

@@ -46,6 +46,9 @@ namespace saf {
 #ifndef EQ_OLA
 #define EQ_OLA 4
 #endif
+#ifndef EQ_BINB
+#define EQ_BINB 4           /* slots whose bin-pair reads are in flight together (bins phase) */
+#endif
 #ifndef EQ_MINWAVES
 #define EQ_MINWAVES 3       /* waves per SIMD the one-output kernel is compiled for (168 registers) */
 #endif
@@ -228,16 +231,16 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
         const bool emit = s0 >= c0;                         /* the warm-up sub-chunk of a later chunk only rebuilds the frame history */
         /* 1. window + fold of the new hops (afSTFT_internal.c:276-301) -> ring position (hop + 6) % ERING */
 #pragma unroll
+        /* (hops beyond the end of a partial last sub-chunk fold the clamped loads into slots nobody reads: no guards, the
+         * sixteen folds are straight-line code) */
         for (int t = 0; t < SUB; t++) {
-            if (t < n) {
-                float fe = 0.0f, fo = 0.0f;
+            float fe = 0.0f, fo = 0.0f;
 #pragma unroll
-                for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
-                const int pos = pN + t >= ERING ? pN + t - ERING : pN + t;
-                float* slot = s_ring + pos * SLOT;
-                if (D == 1 && uni) { fe *= sc[0]; fo *= sc[0]; }      /* uniform channel: the fold IS the frame; its gain goes in here */
-                slot[fn] = fe; slot[128 + fn] = fo;
-            }
+            for (int i = 0; i < 5; i++) { fe = fmaf(xin[t + 2 * i], w[2 * i], fe); fo = fmaf(xin[t + 2 * i + 1], w[2 * i + 1], fo); }
+            const int pos = pN + t >= ERING ? pN + t - ERING : pN + t;
+            float* slot = s_ring + pos * SLOT;
+            if (D == 1 && uni) { fe *= sc[0]; fo *= sc[0]; }      /* uniform channel: the fold IS the frame; its gain goes in here */
+            slot[fn] = fe; slot[128 + fn] = fo;
         }
         /* the last sub-chunk records the new input history (the last 15 hops); a partial one re-reads them below */
         const bool more = s0 + SUB < H;
@@ -288,13 +291,21 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
             for (int d = 0; d < D; d++) { hg1[d] = GS * s_gain[d][2 * hb - 1]; hg2[d] = GS * s_gain[d][2 * hb]; hgm[d] = 0.5f * GS * s_gain[d][132 - hb]; }
             /* general items: lane = bin pair (k, 128-k), see the derivation of ca / cb / cg above */
             if (mkOn) {
-#pragma unroll 4
-                for (int i = 0; i < SUB / 2; i++) {
-                    const int u = 8 * wv + i;
-                    if (u < n) {
+                /* four slots at a time: their eight LDS reads first (one wait), then the arithmetic and the writes */
+#pragma unroll
+                for (int i0 = 0; i0 < SUB / 2; i0 += EQ_BINB) {
+                    float2 bZk[EQ_BINB], bZm[EQ_BINB];
+#pragma unroll
+                    for (int i = 0; i < EQ_BINB; i++) {
+                        const float* slot = lag_slot(8 * wv + i0 + i);     /* (slots beyond the end of a partial last sub-chunk: transformed too, read by nobody) */
+                        bZk[i] = *reinterpret_cast<const float2*>(slot + 2 * mk);
+                        bZm[i] = *reinterpret_cast<const float2*>(slot + 2 * ((128 - mk) & 127));
+                    }
+#pragma unroll
+                    for (int i = 0; i < EQ_BINB; i++) {
+                        const int u = 8 * wv + i0 + i;
                         float* slot = lag_slot(u);
-                        const float2 Zk = *reinterpret_cast<const float2*>(slot + 2 * mk);
-                        const float2 Zm = *reinterpret_cast<const float2*>(slot + 2 * ((128 - mk) & 127));
+                        const float2 Zk = bZk[i], Zm = bZm[i];
 #pragma unroll
                         for (int d = 0; d < D; d++) {
                             float* o = d == 0 ? slot : s_out1 + u * SLOT;
@@ -361,20 +372,24 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
 #pragma unroll
                 for (int d = 0; d < D; d++) {
 #pragma unroll
+                    /* the frames of the pass first (one LDS wait), then the sums; frames beyond the end of a partial pass are read
+                     * (slots nobody uses) but neither stored nor kept (see the history update below) */
                     for (int u = 0; u < EQ_OLA; u++) {
-                        if (u < nh) {
-                            const int uu = half * EQ_OLA + u;
-                            const float* slot = (d == 0 || uni) ? lag_slot(uu) : s_out1 + uu * SLOT;
-                            if (D == 1) { gl[d][9 + u] = slot[tid]; gr[d][9 + u] = slot[128 + tid]; }
-                            else { gl[d][9 + u] = slot[tid] * sc[d]; gr[d][9 + u] = slot[128 + tid] * sc[d]; }
-                            float acc = 0.0f;
+                        const int uu = half * EQ_OLA + u;
+                        const float* slot = (d == 0 || uni) ? lag_slot(uu) : s_out1 + uu * SLOT;
+                        if (D == 1) { gl[d][9 + u] = slot[tid]; gr[d][9 + u] = slot[128 + tid]; }
+                        else { gl[d][9 + u] = slot[tid] * sc[d]; gr[d][9 + u] = slot[128 + tid] * sc[d]; }
+                    }
 #pragma unroll
-                            for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
-                            if (emit) {      /* uniform 64-bit base (scalar registers) + 4 * tid */
-                                const unsigned long long zb = (unsigned long long)(zBase[d] + (long long)(s0 + uu) * SAF_HOP);
-                                const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)zb), hi = __builtin_amdgcn_readfirstlane((unsigned)(zb >> 32));
-                                *reinterpret_cast<float*>(reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo) + (unsigned)(tid * 4)) = acc;
-                            }
+                    for (int u = 0; u < EQ_OLA; u++) {
+                        const int uu = half * EQ_OLA + u;
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
+                        if (emit && u < nh) {      /* uniform 64-bit base (scalar registers) + 4 * tid */
+                            const unsigned long long zb = (unsigned long long)(zBase[d] + (long long)(s0 + uu) * SAF_HOP);
+                            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)zb), hi = __builtin_amdgcn_readfirstlane((unsigned)(zb >> 32));
+                            *reinterpret_cast<float*>(reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo) + (unsigned)(tid * 4)) = acc;
                         }
                     }
                     if (nh == EQ_OLA) {
