@@ -290,7 +290,7 @@ def run_rank(args):
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source}
             if dom == "afstft_eq":
-                roof["limiter"] = ("vector-instruction issue, not HBM: ~842 M VALU wave-instructions per launch of 16 384 frames = 0.5 of the chip's "
+                roof["limiter"] = ("vector-instruction issue, not HBM: ~813 M VALU wave-instructions per launch of 16 384 frames = 0.5 of the chip's "
                                    "measured vector-issue rate (profiles/r02_pmc_summary.txt, r02_valu_rate.txt); the kernel moves 262 144 B per frame, the floor of the path")
             gm = per.get("band_gemm")
             if gm:
