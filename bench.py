@@ -20,7 +20,7 @@ channel runs afSTFT analysis -> per-band gains -> afSTFT synthesis in one kernel
 time-domain MFMA GEMM applies the dense decoder.  It holds for any per-band order / max-rE / normalisation assignment.
 Extra keys (same sizes): `default_dispatch` (what the library does by default on THIS workload: its weights are the same
 in every band, so the transforms are skipped), `per_band_orders_workload` (every band its own order: default dispatch =
-the general form), `two_decoder_workload` (SAD below / EPAD above the transition: two dense matrices),
+the general form), `two_decoder_workload` (SAD below / EPAD above the transition: two dense matrices; default = the two-output equaliser form, `transform_form` beside it),
 `transform_path` (round 1's three-kernel path, spectra through HBM), `other_configs` (BASELINE configs[2..4], short
 regions), `cpu_baseline` (1 core) and `cpu_baseline_allcores` (one oracle instance per core).
 """
@@ -243,12 +243,12 @@ def run_rank(args):
         decs2 = [make_decoder(api.AmbiDec, 1, 3) for _ in range(nI)]          # SAD below / EPAD above 800 Hz: two dense matrices
         batch2 = api.AmbiDecBatch(decs2, nF)
         TRK = ("afstft_analysis", "band_gemm", "afstft_synthesis")
-        dt, per = timed_region(batch2, 1, TRK, args.steps, w2, expect_path=0)
-        extra["two_decoder_workload"] = region_dict(dt, per, "SAD below / EPAD above the 800 Hz transition (two different dense matrices), library default: the transform path "
-                                                             "(measured faster than the two-output equaliser form below)")
-        dt, per = timed_region(batch2, 2, EQK, args.steps, w2)
-        extra["two_decoder_workload"]["equaliser_form"] = region_dict(dt, per, "mode 2: the equaliser kernel emits two signals per channel (1 forward, 2 inverse transforms), the time-domain GEMM "
-                                                                               "has two terms; algorithmic traffic 6 x 131 072 B per frame")
+        dt, per = timed_region(batch2, 1, EQK, args.steps, w2, expect_path=1)
+        extra["two_decoder_workload"] = region_dict(dt, per, "SAD below / EPAD above the 800 Hz transition (two different dense matrices), library default = the equaliser path: the "
+                                                             "kernel emits two signals per channel (1 forward, 2 inverse transforms), the time-domain GEMM has two terms; "
+                                                             "algorithmic traffic 6 x 131 072 B per frame")
+        dt, per = timed_region(batch2, 0, TRK, args.steps, w2)
+        extra["two_decoder_workload"]["transform_form"] = region_dict(dt, per, "mode 0: the same workload on the three-kernel transform path")
         del batch2, decs2
     L.saf_hip_ambi_dec_setTimeDomainPath(1)
 

@@ -202,9 +202,9 @@ struct DecPipeline {
     }
 
     /* Do the two decoder slots of any instance hold different dense matrices?  Then the equaliser kernel has to emit two
-     * signals per channel (one per dense matrix: 1 forward, 2 inverse transforms, 42 KB of LDS per workgroup) and the GEMM has
-     * two terms: measured 3.0 M frames/s against 3.6 M on the transform path (profiles/r02_*), so the default mode sends such
-     * pipelines down the transform path; mode 2 still runs them on the equaliser path (parity-tested). */
+     * signals per channel (one per dense matrix: 1 forward, 2 inverse transforms, 40 KB of LDS per workgroup) and the GEMM has
+     * two terms: 3.86 M frames/s against 3.69 M on the transform path (same box, profiles/r02_*) since the kernel's tables moved
+     * into the slot pads (four workgroups per CU instead of three). */
     bool two_dense_matrices()
     {
         bool two = false;
@@ -394,7 +394,6 @@ struct DecPipeline {
         /* the time-domain GEMM writes the caller's block with 16-byte stores */
         bool eq = !bin && mode != 0 && synDomain != DOM_LS &&
                   ((out_inst | out_frame | out_ch) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0;
-        if (eq && mode == 1 && two_dense_matrices()) eq = false;      /* measured: see two_dense_matrices() */
         if (eq) {
             refresh_eq(mode);
             const long long zCh = (long long)Hmax * SAF_HOP, zInst = (long long)SAF_MAXCH * zCh, zD = (long long)nInst * zInst;

@@ -65,10 +65,19 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
 {
     __shared__ __attribute__((aligned(16))) float s_ring[ERING * SLOT];
     __shared__ __attribute__((aligned(16))) float s_out1[D > 1 ? SUB * SLOT : 4];      /* frames of the second output */
-    __shared__ float2 s_low[LOWR][4];
+    /* The two-output kernel keeps its small tables in the 64-byte pads of the slots (floats 256..271 of a slot are touched by no
+     * transform): the W128 twiddles [p][j] in the pads of ring slots 0..15, e^{-2 pi i k/256} (k < 8) in that of slot 16, the
+     * bins-1..4 history in the pads of the second output's slots.  42.4 -> 40.3 KB: four workgroups per CU instead of three. */
+    constexpr bool PADTAB = D > 1;
+    __shared__ float2 s_low_[PADTAB ? 1 : LOWR][4];
     __shared__ float s_gain[D][136];
-    __shared__ float2 s_twJ[8 * 16];
-    __shared__ float2 s_twl[8];                              /* e^{-2 pi i k / 256}, k < 8 (bins 1..4) */
+    __shared__ float2 s_twJ_[PADTAB ? 1 : 8 * 16];
+    __shared__ float2 s_twl_[PADTAB ? 1 : 8];                /* e^{-2 pi i k / 256}, k < 8 (bins 1..4) */
+    auto lowp = [&](int h, int b) -> float2& {               /* bins 1..4 (b = 0..3) of hop h (mod LOWR) */
+        const int hh = h & (LOWR - 1);
+        return PADTAB ? *reinterpret_cast<float2*>(s_out1 + (hh & 15) * SLOT + 256 + 8 * (hh >> 4) + 2 * b) : s_low_[PADTAB ? 0 : hh][b];
+    };
+    auto twl = [&](int k) -> float2& { return PADTAB ? *reinterpret_cast<float2*>(s_ring + 16 * SLOT + 256 + 2 * k) : s_twl_[PADTAB ? 0 : k]; };
 
     const EqLaunch& e = g.e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -84,8 +93,9 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
     const bool last = H == e.H;                              /* the workgroup that owns the end of the launch records the state */
     const bool uni = e.uniform != nullptr && e.uniform[inst * SAF_MAXCH + ch] != 0;
 
-    load_twiddles_pj(s_twJ, g.twJ, tid);
-    if (tid < 8) s_twl[tid] = g.tw256[tid];
+    if (PADTAB) *reinterpret_cast<float2*>(s_ring + (tid & 15) * SLOT + 256 + 2 * (tid >> 4)) = g.twJ[tid];      /* [p][j], p = tid & 15 */
+    else load_twiddles_pj(s_twJ_, g.twJ, tid);
+    if (tid < 8) twl(tid) = g.tw256[tid];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         const float* gsrc = e.gains + (((long long)inst * D + d) * SAF_MAXCH + ch) * 136;
@@ -123,7 +133,9 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
 
     /* ---- FFT role: thread = (hop of the sub-chunk, lane j of its group of 8) ---- */
     const int ff = tid >> 3, fj = tid & 7;
-    const TwCol twJ{ s_twJ + fj };
+    /* twiddle p of this lane: s_twJ[p * 8 + fj], or float2 fj of the pad of ring slot p */
+    struct TwAny { const float2* p; int stride; __device__ __forceinline__ float2 operator[](int i) const { return p[i * stride]; } };
+    const TwAny twJ{ PADTAB ? reinterpret_cast<const float2*>(s_ring + 256) + fj : s_twJ_ + fj, PADTAB ? SLOT / 2 : 8 };
 
     /* ---- main-pass role: lane = bin pair (k, 128-k), k = lane + 1 ---- */
     const int mk = lane == 0 ? 0 : lane + 1;                 /* lane 0: DC / Nyquist (k = 0); lanes 1..3 idle (bins 2..4 are hybrid items) */
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
 #pragma unroll
         for (int i = 0; i < SUB; i++) xin[9 + i] = ld_at(__builtin_amdgcn_readlane(offN, i)) * scale;
     }
-    __syncthreads();                                         /* s_gain, s_twJ */
+    __syncthreads();                                         /* s_gain, the twiddle tables */
     /* Bins k and 128-k (k >= 5) between the forward and the inverse transform: real-FFT split (kiss_fftr.c:86-123), the gains
      * g_k, g_m of their two bands, half-complex packing (kiss_fftr.c:125-161).  With a = Z[k], b = conj Z[128-k], W = e^{-2 pi i k/256}:
      *     2 X[k] = a (1 - iW) + b (1 + iW),      2 X[128-k] = conj( a (1 + iW) + b (1 - iW) )
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
         float* slot = s_ring + ff * SLOT;
         fft128_slot<false>(slot, fj, twJ, 0);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (fj >= 1 && fj <= 4) s_low[(hs + ff - 6 + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, s_twl[fj]);
+        if (fj >= 1 && fj <= 4) lowp(hs + ff - 6 + 64, fj - 1) = ana_bin_lo(slot, 0, fj, twl(fj));
     }
     lds_barrier();      /* the first fold below wraps into ring positions 0 and 1 (hops 14, 15): the warm-up FFTs must be done with them */
 
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
                 float* slot = s_ring + (pN + ff >= ERING ? pN + ff - ERING : pN + ff) * SLOT;
                 fft128_slot<false>(slot, fj, twJ, 0);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (fj >= 1 && fj <= 4) s_low[(s0 + ff + 64) & (LOWR - 1)][fj - 1] = ana_bin_lo(slot, 0, fj, s_twl[fj]);
+                if (fj >= 1 && fj <= 4) lowp(s0 + ff + 64, fj - 1) = ana_bin_lo(slot, 0, fj, twl(fj));
             }
             STAMP(2);                                        /* FFT */
             lds_barrier();                                   /* B2 */
@@ -280,12 +292,12 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kerne
             const bool hOn = lane < 32 && uh < n;
             float* hslot = lag_slot(uh < n ? uh : 0);
             const int hl = s0 - 3 + uh + 64;
-            const float2 hDk = s_low[hl & (LOWR - 1)][hb - 1];
-            const float2 hS0 = s_low[(hl + 3) & (LOWR - 1)][hb - 1], hS2 = s_low[(hl + 1) & (LOWR - 1)][hb - 1];
-            const float2 hS4 = s_low[(hl - 1) & (LOWR - 1)][hb - 1], hS6 = s_low[(hl - 3) & (LOWR - 1)][hb - 1];
+            const float2 hDk = lowp(hl, hb - 1);
+            const float2 hS0 = lowp(hl + 3, hb - 1), hS2 = lowp(hl + 1, hb - 1);
+            const float2 hS4 = lowp(hl - 1, hb - 1), hS6 = lowp(hl - 3, hb - 1);
             const float2 hZk = *reinterpret_cast<const float2*>(hslot + 2 * hb);
             const float2 hZm = *reinterpret_cast<const float2*>(hslot + 2 * (128 - hb));
-            const float2 hW = s_twl[hb];
+            const float2 hW = twl(hb);
             float hg1[D], hg2[D], hgm[D];
 #pragma unroll
             for (int d = 0; d < D; d++) { hg1[d] = GS * s_gain[d][2 * hb - 1]; hg2[d] = GS * s_gain[d][2 * hb]; hgm[d] = 0.5f * GS * s_gain[d][132 - hb]; }

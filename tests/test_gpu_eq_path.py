@@ -74,8 +74,8 @@ def test_equaliser_path_vs_oracle_and_transform_path(saf, orc, path, F, order, p
         path(mode)
         g = make(saf.AmbiDec, F, order, preset, m0, m1, norm, chord, orders, **kw)
         outs[mode] = run(g, x, nLS, F)
-        # default mode: two different dense decoder matrices go down the transform path (measured faster); mode 2 forces the equaliser
-        assert g.lastPath() == (0 if mode == 0 or (mode == 1 and m0 != m1) else 1)
+        # modes 1 and 2 take the equaliser path (two different dense decoder matrices: its two-output form)
+        assert g.lastPath() == (0 if mode == 0 else 1)
         assert relrms(outs[mode], yo) < TOL and relrms(outs[mode], yo) < 3e-6, mode
     assert relrms(outs[1], outs[0]) < 3e-6 and relrms(outs[2], outs[0]) < 3e-6
 
@@ -106,8 +106,8 @@ def test_equaliser_path_parameter_changes_and_switch_to_transform(saf, orc, path
     for sched in ([1] * 24, [2] * 24, [1] * 9 + [0] * 15, [2] * 14 + [0] * 5 + [1] * 5):
         yg, d = go(saf.AmbiDec, sched)
         assert relrms(yg, yo) < 3e-6, sched
-        # a pipeline that ran the transform path stays on it; two different dense matrices: default mode = transform path
-        assert d.lastPath() == (0 if (0 in sched or (m0 != m1 and 1 in sched)) else 1)
+        # a pipeline that ran the transform path stays on it
+        assert d.lastPath() == (0 if 0 in sched else 1)
 
 
 def test_equaliser_path_missing_and_extra_channels(saf, orc, path):
@@ -144,7 +144,7 @@ def test_equaliser_path_batch_split_invariance_and_strides(saf, orc, path):
                 bt.process_ptr(d_in[:, f0:].data_ptr(), st, d_out[:, f0:].data_ptr(), st, n)
                 f0 += n
             torch.cuda.synchronize()
-            assert bt.lastPath() == (1 if mode == 2 else 0)      # mixed decoders in the batch: default mode = transform path
+            assert bt.lastPath() == (0 if mode == 0 else 1)      # mixed decoders in the batch: the two-output equaliser form
             res[(mode, split)] = d_out.cpu().numpy()
         assert np.array_equal(res[(mode, (nF,))], res[(mode, (1, 2, 3))]), mode
     orcs = [make(orc.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs]
