@@ -3,8 +3,8 @@
  *
  *   cov_update_kernel  per band  Cx <- a*Cx + (1-a) * X X^H  over the T time slots of a frame (powermap.c:258-267:
  *                      cblas_cgemm NoTrans/ConjTrans + sscal + saxpy), frame after frame inside one launch so the
- *                      4.4 MB of covariance matrices cross HBM once per call.  One workgroup per band, a 16 x 16 thread
- *                      grid of 4 x 4 register blocks; the frame's [nSH x T] spectra tile is staged in LDS.
+ *                      4.4 MB of covariance matrices cross HBM once per call.  One workgroup per band and 32 x 32 quadrant, a
+ *                      16 x 16 thread grid of 2 x 2 register blocks; up to 128 time slots of spectra staged in LDS per round.
  *   cgrp_kernel        C_grp = sum_band 1e3*EQ_b * Cx_b (top-left block of the band's order), bands in ascending order
  *                      (powermap.c:281-289).  Only Re(C_grp) is kept: the PWD map is y^T C y with a REAL steering
  *                      vector, so Im(C) cannot reach the real part.
@@ -17,76 +17,90 @@ namespace saf {
 
 struct CovArgs { CovLaunch l; };
 
+/* grid (band, quadrant): a workgroup owns one 32 x 32 quadrant of the band's covariance matrix, a 16 x 16 thread grid of
+ * 2 x 2 register blocks (rows i, i + 16 / columns j, j + 16 of the quadrant: consecutive lanes read consecutive LDS rows whose
+ * stride is odd in 8-byte words, conflict-free).  Rounds of up to COV_SLOTS time slots: the rows of the quadrant's two channel
+ * groups are staged in LDS by ONE wave of loads, then the frames are multiplied out of LDS one after the other with the
+ * reference's update per frame (same arithmetic per matrix element as one workgroup per band: 4 x the workgroups, a quarter of
+ * the arithmetic each; one workgroup per band with one frame per round was 32 us, latency- and issue-bound on half the chip). */
+#define COV_SLOTS 128
 __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
 {
-    __shared__ float2 s_x[64][17];                /* [ch][t], T <= 16, padded */
+    extern __shared__ float2 s_x[];                          /* [64][ld]: rows 0..31 = the quadrant's i channels, 32..63 = its j channels */
     const CovLaunch& l = a.l;
     const int band = blockIdx.x;
+    const int qi = (blockIdx.y >> 1) * 32, qj = (blockIdx.y & 1) * 32;
     const int tid = threadIdx.x;
-    const int bi = (tid >> 4) * 4, bj = (tid & 15) * 4;      /* this thread's 4 x 4 block */
+    const int ti = tid >> 4, tj = tid & 15;                  /* rows ti, ti + 16 and columns tj, tj + 16 of the quadrant */
     const int nSH = l.nSH, T = l.T;
+    if (qi >= nSH || qj >= nSH) return;                      /* (uniform) nothing of this quadrant exists */
+    const int fpr = COV_SLOTS / T;                            /* frames per round */
+    const int ld = fpr * T + 1;
     float2* C = l.Cx + (long long)band * 64 * 64;
-    float2 c[4][4];
+    float2 c[2][2];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 2; u++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) c[u][v] = (bi + u < nSH && bj + v < nSH) ? C[(bi + u) * 64 + bj + v] : make_float2(0.f, 0.f);
+        for (int v = 0; v < 2; v++) {
+            const int i = qi + ti + 16 * u, j = qj + tj + 16 * v;
+            c[u][v] = (i < nSH && j < nSH) ? C[i * 64 + j] : make_float2(0.f, 0.f);
+        }
     const float2* X = l.X + (long long)band * l.x_band;
     const float al = l.alpha, be = 1.0f - l.alpha;
-    /* this thread's elements of a frame's [64 x T] tile (T <= 16: at most 4 per thread); loads are unconditional (rows
-     * beyond nSH re-read row nSH-1 and are zeroed) and the NEXT frame's are issued before the current frame is multiplied */
-    int tch[4], tt[4]; bool ton[4];
+    for (int f0 = 0; f0 < l.nFrames; f0 += fpr) {
+        const int nf = min(fpr, l.nFrames - f0), K = nf * T;  /* slots of this round */
+        __syncthreads();
+        /* unconditional loads (rows beyond nSH re-read row nSH-1 and are zeroed, slots beyond K re-read slot K-1 and are not
+         * used), all issued before the first LDS write */
+        float2 pre[COV_SLOTS * 64 / 256];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int idx = tid + 256 * q;
-        ton[q] = idx < 64 * T;
-        tch[q] = ton[q] ? idx / T : 0; tt[q] = ton[q] ? idx - tch[q] * T : 0;
-    }
-    float2 pre[4];
-    auto fetch = [&](int f) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int chc = tch[q] < nSH ? tch[q] : nSH - 1;
-            pre[q] = X[(long long)chc * l.x_ch + f * T + tt[q]];
+        for (int q = 0; q < COV_SLOTS * 64 / 256; q++) {
+            const int idx = tid + 256 * q, r = idx / COV_SLOTS, t = idx - r * COV_SLOTS;
+            const int ch = r < 32 ? qi + r : qj + r - 32;
+            pre[q] = X[(long long)(ch < nSH ? ch : nSH - 1) * l.x_ch + f0 * T + (t < K ? t : K - 1)];
         }
-    };
-    fetch(0);
-    for (int f = 0; f < l.nFrames; f++) {
+#pragma unroll
+        for (int q = 0; q < COV_SLOTS * 64 / 256; q++) {
+            const int idx = tid + 256 * q, r = idx / COV_SLOTS, t = idx - r * COV_SLOTS;
+            const int ch = r < 32 ? qi + r : qj + r - 32;
+            if (t < K) s_x[r * ld + t] = ch < nSH ? pre[q] : make_float2(0.f, 0.f);
+        }
         __syncthreads();
+        for (int f = 0; f < nf; f++) {
+            float2 n[2][2];
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (ton[q]) s_x[tch[q]][tt[q]] = tch[q] < nSH ? pre[q] : make_float2(0.f, 0.f);
-        __syncthreads();
-        fetch(f + 1 < l.nFrames ? f + 1 : f);
-        float2 n[4][4];
+            for (int u = 0; u < 2; u++)
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+                for (int v = 0; v < 2; v++) n[u][v] = make_float2(0.f, 0.f);
+#pragma unroll 8
+            for (int t = f * T; t < f * T + T; t++) {
+                float2 xi[2], xj[2];
 #pragma unroll
-            for (int v = 0; v < 4; v++) n[u][v] = make_float2(0.f, 0.f);
-        for (int t = 0; t < T; t++) {
-            float2 xi[4], xj[4];
+                for (int u = 0; u < 2; u++) { xi[u] = s_x[(ti + 16 * u) * ld + t]; xj[u] = s_x[(32 + tj + 16 * u) * ld + t]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { xi[u] = s_x[bi + u][t]; xj[u] = s_x[bj + u][t]; }
+                for (int u = 0; u < 2; u++)
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+                    for (int v = 0; v < 2; v++) {        /* x_i * conj(x_j) */
+                        n[u][v].x = fmaf(xi[u].x, xj[v].x, n[u][v].x); n[u][v].x = fmaf(xi[u].y, xj[v].y, n[u][v].x);
+                        n[u][v].y = fmaf(xi[u].y, xj[v].x, n[u][v].y); n[u][v].y = fmaf(-xi[u].x, xj[v].y, n[u][v].y);
+                    }
+            }
 #pragma unroll
-                for (int v = 0; v < 4; v++) {        /* x_i * conj(x_j) */
-                    n[u][v].x = fmaf(xi[u].x, xj[v].x, n[u][v].x); n[u][v].x = fmaf(xi[u].y, xj[v].y, n[u][v].x);
-                    n[u][v].y = fmaf(xi[u].y, xj[v].x, n[u][v].y); n[u][v].y = fmaf(-xi[u].x, xj[v].y, n[u][v].y);
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int v = 0; v < 2; v++) {
+                    c[u][v].x = c[u][v].x * al; c[u][v].y = c[u][v].y * al;                     /* cblas_sscal */
+                    c[u][v].x = fmaf(be, n[u][v].x, c[u][v].x); c[u][v].y = fmaf(be, n[u][v].y, c[u][v].y);   /* cblas_saxpy */
                 }
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int v = 0; v < 4; v++) {
-                c[u][v].x = c[u][v].x * al; c[u][v].y = c[u][v].y * al;                     /* cblas_sscal */
-                c[u][v].x = fmaf(be, n[u][v].x, c[u][v].x); c[u][v].y = fmaf(be, n[u][v].y, c[u][v].y);   /* cblas_saxpy */
-            }
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 2; u++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) if (bi + u < nSH && bj + v < nSH) C[(bi + u) * 64 + bj + v] = c[u][v];
+        for (int v = 0; v < 2; v++) {
+            const int i = qi + ti + 16 * u, j = qj + tj + 16 * v;
+            if (i < nSH && j < nSH) C[i * 64 + j] = c[u][v];
+        }
 }
 
 void launch_cov_update(const CovLaunch& l)
@@ -94,8 +108,12 @@ void launch_cov_update(const CovLaunch& l)
     if (l.nFrames <= 0) return;
     if (l.T > 16) SAF_FATAL("powermap: more than 16 time slots per frame are not supported (frame size <= 2048)");
     CovArgs a; a.l = l;
+    const size_t lds = sizeof(float2) * 64 * ((size_t)(COV_SLOTS / l.T) * l.T + 1);
+    /* 66 KB of dynamic LDS: above the 64 KB a kernel gets without asking (set once; thread-safe static initialisation) */
+    static const int attr_set = []() { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cov_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (COV_SLOTS + 1) * (int)sizeof(float2))); return 1; }();
+    (void)attr_set;
     KernelTimer kt("cov_update");
-    hipLaunchKernelGGL(cov_update_kernel, dim3(SAF_NBANDS), dim3(256), 0, stream(), a);
+    hipLaunchKernelGGL(cov_update_kernel, dim3(SAF_NBANDS, 4), dim3(256), lds, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 
