@@ -44,7 +44,7 @@ namespace saf {
                          * group stay 16 banks apart across the wrap) */
 #define LOWR  32        /* hops of bins 1..4 kept for the hybrid FIR (power of two >= 16 + 7) */
 #ifndef EQ_OLA
-#define EQ_OLA 4
+#define EQ_OLA 16          /* frames per overlap-add pass: their LDS reads are issued together, the history shifts once per pass */
 #endif
 #ifndef EQ_BINB
 #define EQ_BINB 4           /* slots whose bin-pair reads are in flight together (bins phase) */
@@ -60,8 +60,17 @@ struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* t
 #define STAMP(i) do { } while (0)
 #endif
 
+/* The load / store optimizer pairs neighbouring 8-byte LDS accesses into ds_read2_b64 / ds_write2_b64.  On gfx950 a ds_read2_b64
+ * costs 9 LDS cycles against 2 x 3 for two ds_read_b64 (ds_write2_b64: 9 against 2 x 5; tools/probes/lds_bank.hip,
+ * profiles/r02_lds_bank.txt), and this kernel keeps the LDS pipe busy 60 % of the time: unpaired it runs 1.8 % faster
+ * (same box: 1.618 -> 1.589 ms).  Device pass only: the host pass does not know the feature. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EQ_NO_DS_PAIRING __attribute__((target("no-load-store-opt")))
+#else
+#define EQ_NO_DS_PAIRING
+#endif
 template <int D>
-__global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) void afstft_eq_kernel(EqArgs g)
+__global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING void afstft_eq_kernel(EqArgs g)
 {
     __shared__ __attribute__((aligned(16))) float s_ring[ERING * SLOT];
     __shared__ __attribute__((aligned(16))) float s_out1[D > 1 ? SUB * SLOT : 4];      /* frames of the second output */
