@@ -125,6 +125,63 @@ def test_ambi_enc_batch_equals_single_handles_and_feeds_ambi_dec(saf, orc):
     saf.set_stream(None)
 
 
+def test_encode_decode_chain_at_the_per_gpu_share_of_2048_sources(saf, orc):
+    """BASELINE configs[4] at its full per-GPU size: 32 scenes x 64 sources (x 8 GPUs = 2048 sources), order 7 encode ->
+    64-loudspeaker decode, 16 blocks of 512 per call, every band its own decoding order.  The oracle is too slow for all of it:
+    scene 0 and scene 31 are checked against it on the first blocks, the rest through properties of the chain — linear in the
+    source signals, scenes independent of each other, and the same stream cut into different calls gives bit-identical output."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    F, nI, nS, nF, order = 512, 32, 64, 16, 7
+    src = orc.table("SphCovering_64_dirs_deg")
+    orders = 1 + (np.arange(133) * 5) % 7
+
+    def mkenc(cls, i):
+        e = cls(F); e.init(48000); e.setOutputOrder(order); e.setNumSources(nS); e.setNormType(1)
+        for s in range(nS):
+            e.setSourceAzi_deg(s, float(src[(s + 7 * i) % 64, 0])); e.setSourceElev_deg(s, float(src[(s + 7 * i) % 64, 1]))
+        return e
+
+    def mkdec(cls):
+        d = cls(F); d.setNormType(1); d.setChOrder(1); d.setMasterDecOrder(order); d.setOutputConfigPreset(29)
+        d.setDecMethod(0, 1); d.setDecMethod(1, 1); d.initCodec(); d.init(48000); d.setDecOrderAllBands(order)
+        for b, o in enumerate(orders):
+            d.setDecOrder(int(o), b)
+        return d
+
+    st = (nF * 64 * F, 64 * F, F)
+
+    def chain(x, split=(nF,)):
+        eb = saf.AmbiEncBatch([mkenc(saf.AmbiEnc, i) for i in range(nI)], nF)
+        db = saf.AmbiDecBatch([mkdec(saf.AmbiDec) for _ in range(nI)], nF)
+        sh = torch.zeros(nI, nF, 64, F, device="cuda"); ls = torch.zeros_like(sh)
+        f0 = 0
+        for n in split:
+            eb.process_ptr(x[:, f0:].data_ptr(), st, nS, sh[:, f0:].data_ptr(), st, 64, n)
+            db.process_ptr(sh[:, f0:].data_ptr(), st, ls[:, f0:].data_ptr(), st, n)
+            f0 += n
+        torch.cuda.synchronize()
+        assert db.lastPath() == 1
+        return ls
+
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    a = torch.rand(nI, nF, nS, F, device="cuda", generator=g) * 2 - 1
+    b = torch.rand(nI, nF, nS, F, device="cuda", generator=g) * 2 - 1
+    ya, yb = chain(a), chain(b)
+    lin = 1.5 * ya - 0.25 * yb
+    assert float((chain(1.5 * a - 0.25 * b) - lin).norm() / lin.norm()) < 1e-6
+    assert torch.equal(chain(a, split=(1, 7, 8)), ya)
+    a2 = a.clone(); a2[9] = b[9]
+    y2 = chain(a2)
+    assert torch.equal(y2[:9], ya[:9]) and torch.equal(y2[10:], ya[10:]) and torch.equal(y2[9], yb[9])
+    for i in (0, nI - 1):
+        oe, od = mkenc(orc.AmbiEnc, i), mkdec(orc.AmbiDec)
+        xa = a[i, :3].cpu().numpy()
+        ref = np.stack([od.process(oe.process(xa[f], 64), 64) for f in range(3)])
+        assert relrms(ya[i, :3].cpu().numpy(), ref) < 1e-5, i
+    saf.set_stream(None)
+
+
 @pytest.mark.parametrize("F,nS,nIn,order,nOut,norm", [(200, 23, 20, 5, 30, 2), (512, 40, 40, 6, 64, 1), (132, 17, 17, 3, 16, 1), (96, 9, 9, 2, 12, 2)])
 def test_ambi_enc_mid_size_scenes_ragged_blocks(saf, orc, F, nS, nIn, order, nOut, norm):
     """Scenes between the two kernel variants' home sizes: block sizes that are not multiples of the 128-column tile,
