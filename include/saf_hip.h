@@ -261,6 +261,18 @@ SAF_API void* saf_hip_ambi_dec_batch_create(void* const* hAmbis, int nInst, int 
 SAF_API void  saf_hip_ambi_dec_batch_destroy(void** const phBatch);
 SAF_API void  saf_hip_ambi_dec_batch_clear(void* const hBatch);
 SAF_API int   saf_hip_ambi_dec_batch_lastPath(void* const hBatch);
+/** Equaliser path, optional: the dense time-domain decode runs BESIDE the filterbank equaliser kernel instead of after it — a
+ *  persistent grid of MFMA workgroups on a second stream takes each instance as soon as its equaliser workgroups have published
+ *  their output (the reference decodes every frame right after transforming it, ambi_dec.c:514-566).  Same arithmetic, same
+ *  results (bit-identical to the two kernels run in sequence; 64 loudspeakers only).  setOverlap: 0 (default) never, 1 for launches
+ *  of >= 3072 (instance, SH channel) pairs, 2 whenever the shape allows (tests).  Off by default: measured slower on MI355X
+ *  (profiles/r03_overlap_experiment.txt).  batch_lastOverlap: 1 when the last call of the batch ran that way;
+ *  batch_decodeGiveUps: how many decode workgroups ever gave up waiting for the equaliser kernel (their blocks were then computed
+ *  by the fix-up launch): 0 in normal operation. */
+SAF_API void  saf_hip_ambi_dec_setOverlap(int mode);
+SAF_API int   saf_hip_ambi_dec_getOverlap(void);
+SAF_API int   saf_hip_ambi_dec_batch_lastOverlap(void* const hBatch);
+SAF_API int   saf_hip_ambi_dec_batch_decodeGiveUps(void* const hBatch);
 SAF_API void  saf_hip_ambi_dec_batch_process(void* const hBatch,
                                              const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride,
                                              float* d_out, long long out_inst_stride, long long out_frame_stride, long long out_ch_stride,

@@ -102,6 +102,10 @@ def load():
     sig("saf_hip_ambi_dec_getTimeDomainPath", ci)
     sig("saf_hip_ambi_dec_lastPath", ci, vp)
     sig("saf_hip_ambi_dec_batch_lastPath", ci, vp)
+    sig("saf_hip_ambi_dec_setOverlap", None, ci)
+    sig("saf_hip_ambi_dec_getOverlap", ci)
+    sig("saf_hip_ambi_dec_batch_lastOverlap", ci, vp)
+    sig("saf_hip_ambi_dec_batch_decodeGiveUps", ci, vp)
     sig("ambi_dec_create", None, C.POINTER(vp))
     sig("ambi_dec_destroy", None, C.POINTER(vp))
     sig("ambi_dec_init", None, vp, ci)

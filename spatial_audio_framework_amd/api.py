@@ -322,6 +322,13 @@ class AmbiDecBatch:
     def lastPath(self):
         return self.L.saf_hip_ambi_dec_batch_lastPath(self.hb)
 
+    def lastOverlap(self):
+        """1: the last call ran the decode kernel beside the equaliser kernel (saf_hip_ambi_dec_setOverlap)"""
+        return self.L.saf_hip_ambi_dec_batch_lastOverlap(self.hb)
+
+    def decodeGiveUps(self):
+        return self.L.saf_hip_ambi_dec_batch_decodeGiveUps(self.hb)
+
     def __del__(self):
         if getattr(self, "hb", None) and C is not None:
             self.L.saf_hip_ambi_dec_batch_destroy(C.byref(self.hb))

@@ -17,6 +17,35 @@ namespace saf {
 #define COEFF1 0.031273141818515176604f   /* afSTFT_internal.h:74 */
 #define COEFF2 0.28127313041521179171f    /* afSTFT_internal.h:75 */
 
+/* Global memory through  uniform 64-bit base (scalar registers) + 32-bit byte offset of the lane.  The base is an
+ * address-space-1 pointer: a pointer that went through an integer (readfirstlane) is otherwise taken for a FLAT address, and a
+ * flat access counts in lgkmcnt as well as vmcnt — every LDS wait behind it would also wait for the HBM round trip. */
+typedef const char __attribute__((address_space(1)))* gbase_t;
+__device__ __forceinline__ gbase_t uniform_gbase(const void* q)
+{
+    const unsigned long long b = (unsigned long long)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return (gbase_t)(((unsigned long long)hi << 32) | lo);
+}
+/* (re-)pin a uniform base to scalar registers after uniform arithmetic on it: the address selection then takes the
+ * "scalar base + 32-bit lane offset" form of global_load / global_store instead of a 64-bit add per lane */
+__device__ __forceinline__ gbase_t uniform_gbase(gbase_t q) { return uniform_gbase((const void*)q); }
+template <typename T> __device__ __forceinline__ T gld(gbase_t b, unsigned off) { return *(const T __attribute__((address_space(1)))*)(b + off); }
+template <typename T> __device__ __forceinline__ void gst(gbase_t b, unsigned off, const T& v) { *(T __attribute__((address_space(1)))*)(b + off) = v; }
+/* (float4 is a class: its copy constructor does not take an address-space-1 reference; the 16-byte forms go through the
+ * native vector type) */
+typedef float saf_v4f __attribute__((ext_vector_type(4)));
+template <> __device__ __forceinline__ float4 gld<float4>(gbase_t b, unsigned off)
+{
+    const saf_v4f v = *(const saf_v4f __attribute__((address_space(1)))*)(b + off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <> __device__ __forceinline__ void gst<float4>(gbase_t b, unsigned off, const float4& v)
+{
+    saf_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    *(saf_v4f __attribute__((address_space(1)))*)(b + off) = w;
+}
+
 /* Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: every barrier would then wait
  * for the prefetched input loads and for the spectra / sample stores still on their way to HBM. */
 __device__ __forceinline__ void lds_barrier()

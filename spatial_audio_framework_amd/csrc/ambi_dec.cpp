@@ -35,6 +35,13 @@ static int g_ambi_dec_frame_size = 128;    /* default of the reference (ambi_dec
  *   2  as 1, but every channel runs the transforms (what holds for ANY per-band order / decoder / weighting assignment) */
 static int g_ambi_dec_time_domain = []() { const char* e = getenv("SAF_HIP_AMBI_DEC_TIME_DOMAIN"); return e ? atoi(e) : 1; }();
 
+/* Decode beside the equaliser (launch_dec_stream): 0 (default) never — the two kernels run one after the other; 1 when the launch
+ * is large enough to fill the chip several times; 2 whenever the shape allows (tests).  Off by default because it is slower on
+ * MI355X (profiles/r03_overlap_experiment.txt): side by side the two kernels take as long as one after the other (the pair is
+ * bound by the 9.8 GB it moves through HBM, not by the vector or matrix pipes), and publishing z per workgroup (an agent-scope
+ * release = L2 write-back per workgroup) costs the equaliser kernel another 0.4 ms. */
+static int g_ambi_dec_overlap = []() { const char* e = getenv("SAF_HIP_AMBI_DEC_OVERLAP"); return e ? atoi(e) : 0; }();
+
 static inline void sleep_ms(int ms) { std::this_thread::sleep_for(std::chrono::milliseconds(ms)); }
 
 struct AmbiDec {
@@ -90,6 +97,10 @@ struct DecPipeline {
     DevBuf<float> zbuf;             /* [eqD][nInst][64][Hmax * 128] */
     DevBuf<float> zsyn[2];          /* ping-pong: [2][nInst][nSH][9][256] synthesised-frame history of z_d (SH domain) */
     DevBuf<int> zerosI;             /* [nInst][maxFrames] "band -> matrix 0" table of the time-domain GEMM */
+    DevBuf<unsigned> eqDone;        /* [nInst] equaliser workgroups finished, monotonic over the overlapped launches */
+    DevBuf<int> eqErr;              /* [2] see DecStreamLaunch::err */
+    unsigned eqDoneBase = 0;
+    int lastOverlap = 0;            /* 1: the last call ran the decode kernel beside the equaliser kernel */
     int zsynPar = 0, eqD = 1;
     std::vector<char> eqDirty, eqTwo;        /* per instance: tables stale; the two decoders are different matrices */
     std::vector<unsigned long long> eqTwoEpoch;
@@ -180,6 +191,7 @@ struct DecPipeline {
                 eqUni.alloc((size_t)nInst * SAF_MAXCH); Mfrag.alloc((size_t)nInst * 2 * 64 * 64); zerosI.alloc((size_t)nInst * maxFrames);
                 stageG.ensure((size_t)2 * SAF_MAXCH * 136); stageM.ensure((size_t)2 * 64 * 64); stageU.ensure(SAF_MAXCH);
                 for (int i = 0; i < 2; i++) zsyn[i].alloc((size_t)2 * nInst * nSH * SAF_SYN_HIST * 256);
+                eqDone.alloc(nInst); eqErr.alloc(2); eqDoneBase = 0;
             }
             (void)oldD;     /* zsyn holds both outputs from the start: a pipeline that goes from one dense matrix to two keeps z_0's history, z_1's starts from zero */
         }
@@ -406,16 +418,35 @@ struct DecPipeline {
             q.z = zbuf.p; q.z_d = zD; q.z_inst = zInst; q.z_ch = zCh;
             q.syn_rd = zsyn[zsynPar].p; q.syn_wr = zsyn[zsynPar ^ 1].p; q.syn_d = synD;
             q.nCh = nSH; q.nInst = nInst; q.H = H;
-            launch_eq(q);
-            st.anaPar ^= 1; zsynPar ^= 1;
             /* out = M_0 z_0 (+ M_1 z_1): "band" = block, columns = the F samples of the block */
             BandGemmLaunch gn{};
             gn.X = zbuf.p; gn.x_inst = zInst; gn.x_band = F; gn.x_row = zCh; gn.nTerms = eqD; gn.x_term = zD;
             gn.Y = d_out; gn.y_inst = out_inst; gn.y_band = out_frame; gn.y_row = out_ch; gn.nRowsY = nLS;
             gn.Afrag = Mfrag.p; gn.a_inst = 2 * 64 * 64; gn.band2mat = zerosI.p;
             gn.nBands = nFrames; gn.nInst = nInst; gn.N = F; gn.nRowsX = nSH;
+            /* Optional (saf_hip_ambi_dec_setOverlap): the decode runs BESIDE the equaliser kernel (persistent MFMA workgroups on the
+             * side stream that take the instances as their equaliser workgroups finish) instead of after it — the reference
+             * decodes each frame right after transforming it (ambi_dec.c:514-566).  The GEMM launch that follows is then the
+             * fix-up: its workgroups leave at once unless a decode workgroup gave up waiting (see launch_dec_stream). */
+            DecStreamLaunch ds{};
+            ds.z = zbuf.p; ds.z_d = zD; ds.z_inst = zInst; ds.z_ch = zCh; ds.D = eqD; ds.nCh = nSH; ds.nInst = nInst;
+            ds.Y = d_out; ds.y_inst = out_inst; ds.y_frame = out_frame; ds.y_row = out_ch;
+            ds.Mfrag = Mfrag.p; ds.m_inst = 2 * 64 * 64; ds.nRowsY = nLS; ds.F = F; ds.nFrames = nFrames;
+            const bool overlap = g_ambi_dec_overlap != 0 && (g_ambi_dec_overlap == 2 || ((long long)nInst * nSH >= 3072 && H >= 32)) &&
+                                 dec_stream_supported(ds);
+            if (overlap) {
+                ds.done = eqDone.p; ds.target = eqDoneBase + (unsigned)nSH; ds.err = eqErr.p;
+                eqDoneBase += (unsigned)nSH;
+                side_fork();
+                launch_dec_stream(ds, side_stream());
+                launch_eq(q, eqDone.p);
+                side_join();
+                gn.runFlag = eqErr.p;
+            } else
+                launch_eq(q);
+            st.anaPar ^= 1; zsynPar ^= 1;
             launch_band_gemm(gn);
-            synDomain = DOM_SH; lastPath = 1;
+            synDomain = DOM_SH; lastPath = 1; lastOverlap = overlap ? 1 : 0;
             return;
         }
         ensure_transform_buffers();
@@ -804,6 +835,18 @@ void saf_hip_ambi_dec_batch_destroy(void** const phBatch)
 }
 void saf_hip_ambi_dec_batch_clear(void* const hBatch) { ((DecPipeline*)hBatch)->clear_state(); }
 int saf_hip_ambi_dec_batch_lastPath(void* const hBatch) { return ((DecPipeline*)hBatch)->lastPath; }
+int saf_hip_ambi_dec_batch_lastOverlap(void* const hBatch) { return ((DecPipeline*)hBatch)->lastOverlap; }
+int saf_hip_ambi_dec_batch_decodeGiveUps(void* const hBatch)
+{
+    DecPipeline* b = (DecPipeline*)hBatch;
+    if (!b->eqErr.p) return 0;
+    int v[2] = { 0, 0 };
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    HIP_CHECK(hipMemcpy(v, b->eqErr.p, sizeof(v), hipMemcpyDeviceToHost));
+    return v[1];
+}
+void saf_hip_ambi_dec_setOverlap(int mode) { g_ambi_dec_overlap = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+int saf_hip_ambi_dec_getOverlap(void) { return g_ambi_dec_overlap; }
 int saf_hip_ambi_dec_lastPath(void* const hAmbi) { AmbiDec* p = (AmbiDec*)hAmbi; return p->pipe ? p->pipe->lastPath : -1; }
 void saf_hip_ambi_dec_batch_process(void* const hBatch,
                                     const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride,

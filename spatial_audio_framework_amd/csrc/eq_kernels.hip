@@ -53,7 +53,8 @@ namespace saf {
 #define EQ_MINWAVES 3       /* waves per SIMD the one-output kernel is compiled for (168 registers) */
 #endif
 
-struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; int chunk; unsigned long long* stamps; };
+struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; int chunk; unsigned long long* stamps;
+                unsigned* done; int prio; };      /* PUBLISH launches: [nInst] counters of finished workgroups (see the end of the kernel) */
 #ifdef EQ_STAMPS        /* diagnostic build only: cycles per phase of every 64th workgroup (tools/eq_stamps.py) */
 #define STAMP(i) do { if (stampOn && lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += t_ - stampT; stampT = t_; } } while (0)
 #else
@@ -69,7 +70,7 @@ struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* t
 #else
 #define EQ_NO_DS_PAIRING
 #endif
-template <int D>
+template <int D, bool PUBLISH>
 __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING void afstft_eq_kernel(EqArgs g)
 {
     __shared__ __attribute__((aligned(16))) float s_ring[ERING * SLOT];
@@ -92,6 +93,11 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING voi
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ch = blockIdx.x, inst = blockIdx.y;
     const int T = e.hopsPerFrame;
+    /* Beside the decode kernel (launch_dec_stream) the waves of this kernel share their SIMDs with MFMA waves that were
+     * dispatched earlier: arbitration is by priority, then age, so at equal priority the MFMA wave takes every issue slot it
+     * can use and the vector waves beside it crawl (tools/probes/corun_clock.hip).  This kernel is the critical path of the
+     * pair: its waves run at a raised priority, the MFMAs fill what they leave. */
+    if (g.prio) __builtin_amdgcn_s_setprio(3);
     /* time chunks (grid z) add parallelism when few (channel, instance) workgroups exist: a chunk that does not start the launch
      * first runs the 16 hops before it without emitting them, which rebuilds its overlap-add history (identical arithmetic:
      * the outputs do not depend on how a launch is cut) */
@@ -129,13 +135,8 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING voi
         const int fr = (int)(((float)h + 0.5f) * invT);
         return (unsigned)(fr * inFrame + (h - fr * T) * SAF_HOP) * 4u;
     };
-    const char* inBaseB;                                    /* uniform: pinned to scalar registers */
-    {
-        const unsigned long long b = (unsigned long long)inBase;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-        inBaseB = reinterpret_cast<const char*>(((unsigned long long)hi << 32) | lo);
-    }
-    auto ld_at = [&](unsigned hopOffBytes) { return *reinterpret_cast<const float*>(inBaseB + (hopOffBytes + offInB)); };
+    const gbase_t inBaseB = uniform_gbase(inBase);          /* uniform: pinned to scalar registers */
+    auto ld_at = [&](unsigned hopOffBytes) { return gld<float>(inBaseB, hopOffBytes + offInB); };
     float w[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) w[k] = g.win[k * SAF_HOP + fn];
@@ -408,9 +409,7 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING voi
 #pragma unroll
                         for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
                         if (emit && u < nh) {      /* uniform 64-bit base (scalar registers) + 4 * tid */
-                            const unsigned long long zb = (unsigned long long)(zBase[d] + (long long)(s0 + uu) * SAF_HOP);
-                            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)zb), hi = __builtin_amdgcn_readfirstlane((unsigned)(zb >> 32));
-                            *reinterpret_cast<float*>(reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo) + (unsigned)(tid * 4)) = acc;
+                            gst<float>(uniform_gbase(zBase[d] + (long long)(s0 + uu) * SAF_HOP), (unsigned)(tid * 4), acc);
                         }
                     }
                     if (nh == EQ_OLA) {
@@ -454,6 +453,19 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING voi
             for (int i = 0; i < 9; i++) { h[i * 256 + tid] = gl[d][i]; h[i * 256 + 128 + tid] = gr[d][i]; }
         }
     }
+    if (PUBLISH) {
+        /* Publish this channel's z to the decode kernel that runs beside this one (launch_dec_stream, gemm_kernels.hip): every
+         * wave's stores drained, workgroup barrier, agent-scope release (write-back of the XCD's L2), then the instance's counter
+         * (MI355X_MICROARCH.md "Valid forms"; the consumer polls, acquires, then loads).  PUBLISH launches have no time chunks:
+         * one workgroup per (channel, instance). */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(g.done + inst, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 static unsigned long long* g_eq_stamps = nullptr;
@@ -465,7 +477,7 @@ static unsigned long long* eq_stamps_buffer()
     return g_eq_stamps;
 }
 
-void launch_eq(const EqLaunch& e)
+void launch_eq(const EqLaunch& e, unsigned* done)
 {
     if (e.H <= 0 || e.nCh <= 0 || e.nInst <= 0) return;
     if (e.D != 1 && e.D != 2) SAF_FATAL("filterbank equaliser: D must be 1 or 2");
@@ -484,15 +496,22 @@ void launch_eq(const EqLaunch& e)
      * Aim at ~1024 workgroups with chunks of >= 64 hops (multiples of 16). */
     g.chunk = e.H;
     const long long wgs = (long long)e.nCh * e.nInst;
-    if (wgs < 512 && e.H >= 128) {
+    if (wgs < 512 && e.H >= 128 && !done) {
         int nChunks = (int)((1024 + wgs - 1) / wgs);
         if (nChunks > e.H / 64) nChunks = e.H / 64;
         if (nChunks > 1) g.chunk = ((e.H + nChunks - 1) / nChunks + SUB - 1) / SUB * SUB;
     }
     const dim3 grid(e.nCh, e.nInst, (e.H + g.chunk - 1) / g.chunk);
     KernelTimer kt("afstft_eq");
-    if (e.D == 1) hipLaunchKernelGGL(afstft_eq_kernel<1>, grid, dim3(128), 0, stream(), g);
-    else          hipLaunchKernelGGL(afstft_eq_kernel<2>, grid, dim3(128), 0, stream(), g);
+    g.done = done;
+    { static const int p = []() { const char* v = getenv("SAF_HIP_EQ_PRIO"); return v ? atoi(v) : -1; }(); g.prio = p >= 0 ? p : (done != nullptr); }
+    if (done) {
+        if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, true>), grid, dim3(128), 0, stream(), g);
+        else          hipLaunchKernelGGL((afstft_eq_kernel<2, true>), grid, dim3(128), 0, stream(), g);
+    } else {
+        if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, false>), grid, dim3(128), 0, stream(), g);
+        else          hipLaunchKernelGGL((afstft_eq_kernel<2, false>), grid, dim3(128), 0, stream(), g);
+    }
     HIP_CHECK(hipGetLastError());
 }
 

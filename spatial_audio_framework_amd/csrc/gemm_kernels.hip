@@ -19,6 +19,7 @@
  */
 #include "saf_hip_common.h"
 #include "mfma_tile.h"
+#include "afstft_device.h"
 
 namespace saf {
 
@@ -65,6 +66,7 @@ template <bool FULL>
 __global__ __launch_bounds__(128, 1) void band_gemm_kernel(GemmArgs a)
 {
     const BandGemmLaunch& g = a.g;
+    if (g.runFlag != nullptr && *g.runFlag == 0) return;      /* fix-up launch behind the fused equaliser + decode kernel: nothing to repair */
     const int inst = blockIdx.y;
     const int lane = threadIdx.x & 63, rt = threadIdx.x >> 6;
     const int kh = lane >> 5;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(128, 1) void band_gemm2_kernel(GemmArgs a)
 {
     constexpr bool FULL = true;          /* complete column tiles only (N % 128 == 0) */
     const BandGemmLaunch& g = a.g;
+    if (g.runFlag != nullptr && *g.runFlag == 0) return;
     const int inst = blockIdx.y;
     const int lane = threadIdx.x & 63, rt = threadIdx.x >> 6;
     const int kh = lane >> 5;
@@ -209,6 +212,180 @@ void launch_band_gemm(const BandGemmLaunch& g)
     } else if (g.nTerms != 1) SAF_FATAL("band gemm: 1 or 2 terms");
     else if (g.N % 128 == 0) hipLaunchKernelGGL(band_gemm_kernel<true>, grid, dim3(128), 0, stream(), a);
     else                     hipLaunchKernelGGL(band_gemm_kernel<false>, grid, dim3(128), 0, stream(), a);
+    HIP_CHECK(hipGetLastError());
+}
+
+/* ========================================================================== */
+/*        the time-domain decode beside the filterbank equaliser kernel       */
+/* ========================================================================== */
+/* The reference decodes the frame it has just transformed while it is in cache (ambi_dec.c:514-566).  Here the equaliser
+ * kernel (eq_kernels.hip) is bound by vector issue and LDS, the decode  out = sum_d M_d z_d  by HBM and the matrix cores: run
+ * one after the other each leaves half the chip idle.  This kernel runs BESIDE the equaliser kernel, on the library's side
+ * stream: a persistent grid of P workgroups (about one per compute unit; a workgroup = 2 waves with at most 184 registers,
+ * so that it fits next to two of the equaliser's 160-register waves on a SIMD and takes one of a CU's six workgroup slots).
+ * Workgroup p takes the items p, p + P, ... — item = G consecutive units of one instance, instances in the order in which the
+ * equaliser kernel's workgroups are dispatched — and before an item it waits for the instance: every equaliser workgroup
+ * publishes its z (stores drained, barrier, agent-scope release) and adds 1 to done[inst]; here one lane polls the counter,
+ * then agent-scope acquire, barrier, plain loads (MI355X_MICROARCH.md "Valid forms").  Nothing depends on dispatch order or
+ * placement: the equaliser workgroups never wait, and at most P slots of the chip are held by waiting workgroups.  A poll
+ * that is not answered within ~2 s (the equaliser kernel was never launched) sets err[0] and the workgroup leaves; the
+ * caller's fix-up launch (launch_band_gemm guarded by err[0]) then computes the output.
+ *
+ * Unit = 128 columns of one block (frame) of one instance; wave = 32 rows x 128 columns on v_mfma_f32_32x32x2_f32 (exact
+ * fp32).  Register-lean on purpose: 64 accumulators + a ring of DEC_RING 16-byte operand loads per lane that is refilled as
+ * it is consumed (band_gemm_kernel double-buffers whole units in 256 registers and owns its SIMD); the matrix sits in LDS in
+ * fragment order (one conflict-free ds_read_b32 per k-pair step). */
+#ifndef DEC_RING
+#define DEC_RING 16             /* operand loads (16 bytes per lane each) in flight per wave */
+#endif
+#ifndef DEC_UNROLL
+#define DEC_UNROLL 4            /* units per trip of the unit loop: inside the straight-line body the compiler counts the loads in
+                                 * flight exactly (s_waitcnt vmcnt(DEC_RING - 1) per step), at the top of a trip it drains them all */
+#endif
+#ifndef DEC_VGPRS
+#define DEC_VGPRS 184
+#endif
+struct DecArgs { DecStreamLaunch l; int nColTiles, unitsPerInst, G, nG, nItems; };
+
+template <int D>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_num_vgpr(DEC_VGPRS))) void dec_stream_kernel(DecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_A[D * 2 * 32 * 64];
+    __shared__ int s_ok;
+    const DecStreamLaunch& l = a.l;
+    const int tid = threadIdx.x, lane = tid & 63, rt = tid >> 6, kh = lane >> 5;
+    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(l.err, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* (a workgroup gives up 2 s later at the earliest) */
+    /* Addressing: every load and store is  uniform 64-bit base (scalar registers) + 32-bit byte offset of the lane.  Step s of a
+     * unit reads rows 2 s + kh: the step part goes into the scalar base, the lane keeps (kh, column).  Steps beyond the last
+     * channel pair re-read that pair (their matrix columns are zero).  With an odd channel count the kh = 1 lanes of the last
+     * pair read row nCh, one beyond the channels: dec_stream_supported requires that row to exist in z (the operators allocate
+     * 64 zero-filled rows per instance); its matrix column is zero.  An instance's z and output blocks span less than 4 GiB. */
+    const int sLast = (l.nCh - 1) >> 1;
+    const unsigned laneA = (unsigned)(kh * l.z_ch + 4 * (lane & 31)) * 4u;
+    const unsigned laneY = (unsigned)((rt * 32 + 4 * kh) * l.y_row + 4 * (lane & 31)) * 4u;
+    const unsigned rowPair = (unsigned)(2 * l.z_ch * 4);     /* bytes between the row pairs of consecutive steps */
+    const long long termB = l.z_d * 4;
+    typedef const float __attribute__((address_space(3)))* lds_cf;
+    const lds_cf As = (lds_cf)s_A + rt * 2048 + lane;
+    constexpr int NS = 32 * D, RING = DEC_RING, UU = DEC_UNROLL;
+    static_assert(NS % RING == 0, "the ring position of a step must not depend on the unit");
+
+    for (int w = blockIdx.x; w < a.nItems; w += gridDim.x) {
+        const int inst = w / a.nG, gi = w - inst * a.nG;
+        __syncthreads();                                        /* the previous item's reads of s_A */
+        {
+            const float4* Ag = reinterpret_cast<const float4*>(l.Mfrag + (long long)inst * l.m_inst);
+#pragma unroll
+            for (int i = 0; i < 8 * D; i++) reinterpret_cast<float4*>(s_A)[tid + 128 * i] = Ag[tid + 128 * i];
+        }
+        if (tid == 0) {
+            int ok = 0;
+            for (int it = 0; it < 1000000; it++) {              /* bounded: ~2 s of 1.7 us naps */
+                const unsigned v = __hip_atomic_load(l.done + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(v - l.target) >= 0) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(64);
+            }
+            if (ok) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                __hip_atomic_store(l.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(l.err + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) return;
+
+        const int u0 = gi * a.G, u1 = min(u0 + a.G, a.unitsPerInst);
+        const gbase_t Zi = uniform_gbase(l.z + (long long)inst * l.z_inst);
+        const gbase_t Yi = uniform_gbase(l.Y + (long long)inst * l.y_inst);
+        auto unit_base = [&](int u) { const int fr = u / a.nColTiles, ct = u - fr * a.nColTiles; return uniform_gbase(Zi + ((long long)fr * l.F + ct * 128) * 4); };
+        /* The operand loads form one stream over (unit, k-pair step), RING steps ahead of the MFMAs: `lp` is the scalar base of
+         * the stream's next load and moves by one row pair per step (steps beyond the last channel pair stay on it: their matrix
+         * columns are zero), to the second term's rows after step 31 and to the next unit after the last step.  (A table of the
+         * 32 row offsets would be loop-invariant: hoisted, it costs 64 scalar registers and pushes the address arithmetic into the
+         * vector unit.) */
+        gbase_t ubL = unit_base(u0), lp = ubL;
+        auto next_load = [&](int j, int uAfter) {               /* j: step of this load within its unit (compile-time constant) */
+            const float4 v = gld<float4>(lp, laneA);
+            if (j == NS - 1) { ubL = unit_base(uAfter); lp = ubL; }
+            else if (D > 1 && j == 31) lp = ubL + termB;
+            else lp += (j & 31) < sLast ? rowPair : 0u;
+            return v;
+        };
+        float4 ring[RING];
+#pragma unroll
+        for (int s = 0; s < RING; s++) ring[s] = next_load(s, u0);
+        for (int ub = u0; ub < u1; ub += UU) {
+#pragma unroll
+            for (int uu = 0; uu < UU; uu++) {
+                const int u = min(ub + uu, u1 - 1);             /* (a short last trip repeats its last unit: same values, same places) */
+                const int uN = min(ub + uu + 1, u1 - 1), uNN = min(ub + uu + 2, u1 - 1);      /* (the last unit re-requests its own first steps: no load under a branch) */
+                Tile128 t;
+                tile_zero(t);
+                float aNext = As[0];
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const float av = aNext;
+                    if (s + 1 < NS) aNext = As[((s + 1) >> 5) * 4096 + ((s + 1) & 31) * 64];      /* [term][row tile][step][lane] */
+                    tile_step(t, av, ring[s % RING]);
+                    /* the refill goes where it is written, behind the MFMAs that read the slot (so that it takes the slot's
+                     * registers): left alone the scheduler either hoists it above them (a second set of registers) or sinks it to
+                     * just before its use (one load in flight instead of DEC_RING) */
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int sn = s + RING;                    /* the stream is RING steps ahead: step sn of this unit, or sn - NS of the next */
+                    ring[s % RING] = next_load(sn % NS, sn < NS ? uN : uNN);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const int fr = u / a.nColTiles, ct = u - fr * a.nColTiles;
+                const gbase_t Y = uniform_gbase(Yi + ((long long)fr * l.y_frame + ct * 128) * 4);
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int rq = (q & 3) + 8 * (q >> 2);      /* row = rt * 32 + 4 * kh + rq */
+                    gst<float4>(Y + (long long)rq * l.y_row * 4, laneY, make_float4(t.c[0][q], t.c[1][q], t.c[2][q], t.c[3][q]));
+                    __builtin_amdgcn_sched_barrier(0);          /* (one address at a time) */
+                }
+            }
+        }
+    }
+}
+
+bool dec_stream_supported(const DecStreamLaunch& l)
+{
+    /* the tile stores 64 rows unguarded and moves 128 columns with 16-byte accesses; with an odd channel count the row behind the
+     * last channel must exist (see the kernel) */
+    if (l.nRowsY != 64 || l.F % 128 != 0 || l.nFrames <= 0 || l.nInst <= 0 || (l.D != 1 && l.D != 2)) return false;
+    if (((l.y_inst | l.y_frame | l.y_row | l.z_inst | l.z_ch | l.z_d | l.m_inst) & 3) || ((uintptr_t)l.Y & 15) || ((uintptr_t)l.z & 15) || ((uintptr_t)l.Mfrag & 15)) return false;
+    if (l.z_ch < 0 || l.y_row < 0 || l.y_frame < 0) return false;
+    const long long rows = l.nCh + (l.nCh & 1);
+    if (rows * l.z_ch > l.z_inst && l.nInst > 1) return false;
+    if ((64 * l.z_ch + (long long)l.nFrames * l.F) * 4 >= (1ll << 32)) return false;
+    if ((64 * l.y_row + (long long)l.nFrames * l.y_frame + l.F) * 4 >= (1ll << 32)) return false;
+    return true;
+}
+
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static int g_dec_P = env_int("SAF_HIP_DEC_WGS", 0), g_dec_G = env_int("SAF_HIP_DEC_G", 0);
+
+void launch_dec_stream(const DecStreamLaunch& l, hipStream_t s)
+{
+    if (!dec_stream_supported(l)) SAF_FATAL("launch_dec_stream: unsupported shape (check dec_stream_supported first)");
+    DecArgs a;
+    a.l = l;
+    a.nColTiles = l.F / 128;
+    a.unitsPerInst = l.nFrames * a.nColTiles;
+    /* G units per item: long enough to amortise the matrix load and the acquire (a unit is ~5 us), short enough that the
+     * workgroups stay close behind the equaliser kernel */
+    a.G = g_dec_G > 0 ? g_dec_G : 16;
+    if (a.G > a.unitsPerInst) a.G = a.unitsPerInst;
+    a.nG = (a.unitsPerInst + a.G - 1) / a.G;
+    a.nItems = l.nInst * a.nG;
+    int P = g_dec_P > 0 ? g_dec_P : 256;                         /* one per compute unit */
+    if (P > a.nItems) P = a.nItems;
+    KernelTimer kt("dec_stream", s);
+    if (l.D == 1) hipLaunchKernelGGL(dec_stream_kernel<1>, dim3(P), dim3(128), 0, s, a);
+    else          hipLaunchKernelGGL(dec_stream_kernel<2>, dim3(P), dim3(128), 0, s, a);
     HIP_CHECK(hipGetLastError());
 }
 

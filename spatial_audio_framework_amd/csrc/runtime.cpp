@@ -49,10 +49,45 @@ hipStream_t stream()
     return g_stream;
 }
 
+/* The side stream carries kernels that run BESIDE one on the main stream (the decode kernel beside the filterbank equaliser of
+ * ambi_dec).  fork: the side stream waits for everything enqueued on the main stream so far; join: the main stream waits for
+ * everything enqueued on the side stream so far.  One event each, re-recorded per use (HIP events may be reused once the wait
+ * that names them has been enqueued). */
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+hipStream_t side_stream()
+{
+    hipStream_t s = __atomic_load_n(&g_side, __ATOMIC_ACQUIRE);
+    if (s) return s;
+    (void)stream();
+    std::lock_guard<std::mutex> lk(g_rt_mutex);
+    if (!g_side) {
+        hipStream_t ns = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
+        __atomic_store_n(&g_side, ns, __ATOMIC_RELEASE);
+    }
+    return g_side;
+}
+void side_fork()
+{
+    hipStream_t s2 = side_stream();
+    HIP_CHECK(hipEventRecord(g_ev_fork, stream()));
+    HIP_CHECK(hipStreamWaitEvent(s2, g_ev_fork, 0));
+}
+void side_join()
+{
+    hipStream_t s2 = side_stream();
+    HIP_CHECK(hipEventRecord(g_ev_join, s2));
+    HIP_CHECK(hipStreamWaitEvent(stream(), g_ev_join, 0));
+}
+
 void set_stream(hipStream_t s)
 {
     std::lock_guard<std::mutex> lk(g_rt_mutex);
     ensure_device_locked();
+    if (g_side) HIP_CHECK(hipStreamSynchronize(g_side));
     if (g_stream && g_own_stream) { HIP_CHECK(hipStreamSynchronize(g_stream)); HIP_CHECK(hipStreamDestroy(g_stream)); }
     g_own_stream = false;
     hipStream_t ns = s;
@@ -65,18 +100,18 @@ static int g_zero_copy = []() { const char* e = getenv("SAF_HIP_ZERO_COPY"); ret
 bool zero_copy_io() { return g_zero_copy != 0; }
 
 /* ---- per-kernel timing ---- */
-struct ProfRec { const char* name; hipEvent_t a, b; };
+struct ProfRec { const char* name; hipEvent_t a, b; hipStream_t s; };
 static bool g_prof = false;
 static std::vector<ProfRec> g_recs;
 static std::mutex g_prof_mutex;          /* launches may come from several host threads while profiling is on */
 
-KernelTimer::KernelTimer(const char* name) : slot(-1)
+KernelTimer::KernelTimer(const char* name, hipStream_t on) : slot(-1)
 {
     if (!g_prof) return;
-    ProfRec r; r.name = name;
+    ProfRec r; r.name = name; r.s = on ? on : stream();
     HIP_CHECK(hipEventCreate(&r.a)); HIP_CHECK(hipEventCreate(&r.b));
     std::lock_guard<std::mutex> lk(g_prof_mutex);
-    HIP_CHECK(hipEventRecord(r.a, stream()));
+    HIP_CHECK(hipEventRecord(r.a, r.s));
     g_recs.push_back(r);
     slot = (int)g_recs.size() - 1;
 }
@@ -84,7 +119,7 @@ KernelTimer::~KernelTimer()
 {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mutex);
-    if (slot < (int)g_recs.size()) HIP_CHECK(hipEventRecord(g_recs[slot].b, stream()));
+    if (slot < (int)g_recs.size()) HIP_CHECK(hipEventRecord(g_recs[slot].b, g_recs[slot].s));
 }
 
 }  // namespace saf

@@ -46,6 +46,9 @@ namespace saf {
 
 /* ---- runtime (runtime.cpp) ---- */
 hipStream_t stream();                 /* stream all library work is enqueued on */
+hipStream_t side_stream();            /* second stream: kernels that run beside one on stream() (fork / join with the two calls below) */
+void        side_fork();              /* work enqueued on side_stream() after this call starts after what is on stream() now */
+void        side_join();              /* work enqueued on stream() after this call starts after what is on side_stream() now */
 void        set_stream(hipStream_t);  /* adopt a caller's stream (e.g. torch's current stream) */
 void        ensure_device();          /* aborts with a clear message when no GPU is usable */
 
@@ -57,7 +60,7 @@ bool zero_copy_io();
 
 /* ---- optional per-kernel timing with HIP events on the library stream (runtime.cpp) ---- */
 struct KernelTimer {            /* RAII: brackets one kernel launch when profiling is enabled */
-    explicit KernelTimer(const char* name);
+    explicit KernelTimer(const char* name, hipStream_t on = nullptr);     /* on: the stream the kernel is launched on (default: stream()) */
     ~KernelTimer();
     int slot;
 };
@@ -167,7 +170,26 @@ struct EqLaunch {
     const float* syn_rd; float* syn_wr; long long syn_d;      /* [d][inst][nCh][9][256] */
     int nCh, nInst, H;
 };
-void launch_eq(const EqLaunch& e);
+/* done != nullptr: every workgroup (one per channel and instance, no time chunks) publishes its z and adds 1 to done[inst] when
+ * it has finished — the decode kernel of launch_dec_stream consumes the instances as they complete */
+void launch_eq(const EqLaunch& e, unsigned* done = nullptr);
+
+/* ---- the time-domain decode  out = sum_d M_d z_d  running BESIDE the equaliser kernel (gemm_kernels.hip) ----
+ * A persistent grid of register-lean MFMA workgroups on the library's second stream: workgroup p takes the work items
+ * p, p + P, ... (item = G column tiles of one instance, instances in launch order), waits until the equaliser workgroups of the
+ * item's instance have all published (done[inst] reaches `target`) and multiplies.  The equaliser is bound by vector issue and
+ * LDS, the decode by HBM and the matrix cores: side by side they share the compute units instead of taking turns. */
+struct DecStreamLaunch {
+    const float* z; long long z_d, z_inst, z_ch;  /* as EqLaunch */
+    int D, nCh, nInst;
+    float* Y; long long y_inst, y_frame, y_row;   /* out[inst*y_inst + frame*y_frame + row*y_row + n], n < F */
+    const float* Mfrag; long long m_inst;         /* dense decoder(s) of an instance in MFMA fragment order: [D][2][32][64] */
+    int nRowsY, F, nFrames;
+    const unsigned* done; unsigned target;
+    int* err;                                     /* [2] [0]: a workgroup gave up waiting in this launch (the caller's fix-up GEMM then runs), [1]: total */
+};
+bool dec_stream_supported(const DecStreamLaunch& l);
+void launch_dec_stream(const DecStreamLaunch& l, hipStream_t s);
 
 /* ---- band-batched real GEMM on MFMA (gemm_kernels.hip) ----
  * For every (inst, band): Y[64 x N] = A[mat(inst,band)][64 x 64] * X[64 x N], N = 2*H floats
@@ -183,6 +205,7 @@ struct BandGemmLaunch {
     /* nTerms = 2:  Y = A_0 X_0 + A_1 X_1  with X_1 = X + x_term and A_1 = the matrix after A_0 (Afrag + 4096 floats) */
     int nTerms = 1; long long x_term = 0;
     int nRowsY = 64;               /* rows of Y that exist: rows beyond are computed (against zero matrix rows) but not stored */
+    const int* runFlag = nullptr;  /* when set: the launch does nothing unless *runFlag != 0 (the fix-up behind launch_eq_dec) */
 };
 void launch_band_gemm(const BandGemmLaunch& g);
 void pack_A(const float* A /* [64][64] row-major, zero padded */, float* Afrag /* [2][32][64] */);

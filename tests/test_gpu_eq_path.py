@@ -22,6 +22,14 @@ def path(saf):
     L.saf_hip_ambi_dec_setTimeDomainPath(1)
 
 
+@pytest.fixture()
+def overlap(saf):
+    from spatial_audio_framework_amd._lib import load
+    L = load()
+    yield L.saf_hip_ambi_dec_setOverlap
+    L.saf_hip_ambi_dec_setOverlap(0)
+
+
 def make(cls, F, order, preset, m0, m1, norm=1, chord=1, orders=None, **kw):
     d = cls(F)
     d.setNormType(norm); d.setChOrder(chord); d.setMasterDecOrder(order); d.setOutputConfigPreset(preset)
@@ -186,7 +194,58 @@ def test_equaliser_path_time_chunks_bit_identical(saf, orc, path, mode):
     saf.set_stream(None)
 
 
-def test_equaliser_path_full_size_properties(saf, path):
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("two", [False, True])
+def test_decode_beside_equaliser_is_bit_identical_to_sequential(saf, orc, path, overlap, mode, two):
+    """The decode kernel running BESIDE the equaliser kernel (persistent MFMA workgroups on the side stream, per-instance
+    counters: launch_dec_stream) gives bit for bit what the two kernels give one after the other — one dense decoder and two
+    (SAD / EPAD), instances with their own per-band orders, a stream cut into three calls, twelve calls in a row on the same
+    buffers (z and the counters are re-used) — and both equal the oracle."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    F, order, nI, nF = 512, 7, 6, 8
+    path(mode)
+    cfgs = [(1, 3 if two else 1, 1 + i % 2, band_orders(7, 40 + i) if i % 3 else None) for i in range(nI)]
+    x = np.stack([frames(700 + i, nF * 64, 512).reshape(nF, 64, 512) for i in range(nI)])
+    d_in = torch.from_numpy(x).cuda()
+    st = (nF * 64 * 512, 64 * 512, 512)
+    res = {}
+    for ov in (0, 2):
+        overlap(ov)
+        for split in ((nF,), (3, 1, 4)):
+            bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+            d_out = torch.zeros(nI, nF, 64, 512, device="cuda")
+            f0 = 0
+            for n in split:
+                bt.process_ptr(d_in[:, f0:].data_ptr(), st, d_out[:, f0:].data_ptr(), st, n)
+                f0 += n
+            torch.cuda.synchronize()
+            assert bt.lastPath() == 1 and bt.lastOverlap() == (1 if ov else 0) and bt.decodeGiveUps() == 0
+            res[(ov, split)] = d_out.cpu().numpy()
+    assert np.array_equal(res[(2, (nF,))], res[(0, (nF,))]) and np.array_equal(res[(2, (3, 1, 4))], res[(0, (nF,))])
+    for i in (0, nI - 1):
+        a, b, n, o = cfgs[i]
+        oc = make(orc.AmbiDec, F, order, 29, a, b, n, 1, o)
+        yo = np.stack([oc.process(x[i, f], 64) for f in range(nF)])
+        assert relrms(res[(2, (nF,))][i], yo) < 3e-6, i
+    # the same buffers again and again, with different input each time (stale data anywhere would show)
+    overlap(2)
+    bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+    overlap(0)
+    bs = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    yo_, ys_ = torch.zeros(nI, nF, 64, 512, device="cuda"), torch.zeros(nI, nF, 64, 512, device="cuda")
+    for it in range(12):
+        xin = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+        overlap(2); bt.process_ptr(xin.data_ptr(), st, yo_.data_ptr(), st, nF)
+        overlap(0); bs.process_ptr(xin.data_ptr(), st, ys_.data_ptr(), st, nF)
+        torch.cuda.synchronize()
+        assert torch.equal(yo_, ys_), it
+    assert bt.decodeGiveUps() == 0
+    saf.set_stream(None)
+
+
+def test_equaliser_path_full_size_properties(saf, path, overlap):
     """bench size (256 instances x 64 blocks, every band its own order): linearity, instance independence, split invariance,
     and agreement with the transform path — the oracle is too slow here"""
     import torch
@@ -221,4 +280,10 @@ def test_equaliser_path_full_size_properties(saf, path):
     del yb, yab, lin, y2, a2
     yt = go(a, 0)
     assert float((ya - yt).norm() / yt.norm()) < 3e-6
+    del yt
+    # the decode kernel beside the equaliser kernel (optional path) at this size: 16 384 equaliser workgroups publishing to 256
+    # persistent decode workgroups — bit for bit the sequential result
+    overlap(2)
+    assert torch.equal(go(a, 1), ya)
+    overlap(0)
     saf.set_stream(None)
