@@ -102,21 +102,67 @@ def cpu_baseline(seconds_budget=8.0):
                       f"{1e3 * f / (n + 8):.3f}/{1e3 * g / (n + 8):.3f}/{1e3 * b / (n + 8):.3f} ms per block)"}
 
 
-def cpu_baseline_allcores(seconds_budget=8.0):
-    """N independent oracle instances, one process pinned to each core this process may run on"""
-    cores = sorted(os.sched_getaffinity(0))
+def cpu_topology():
+    """physical cores of this process's affinity mask (first hardware thread of every (package, core) pair) and the cgroup CPU quota"""
+    aff = sorted(os.sched_getaffinity(0))
+    first = {}
+    for c in aff:
+        try:
+            base = Path(f"/sys/devices/system/cpu/cpu{c}/topology")
+            key = (int((base / "physical_package_id").read_text()), int((base / "core_id").read_text()))
+        except Exception:
+            key = (0, c)
+        first.setdefault(key, c)
+    quota = None
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = Path(f).read_text().split()
+            if f.endswith("cpu.max"):
+                quota = None if t[0] == "max" else float(t[0]) / float(t[1])
+            else:
+                q = float(t[0]); per = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                quota = None if q <= 0 else q / per
+            break
+        except Exception:
+            continue
+    return aff, sorted(first.values()), quota
+
+
+def cpu_point(cores, seconds_budget):
+    """one oracle process pinned to each of `cores`; (frames/s of the set, frames, slowest seconds) or None"""
     procs = [subprocess.Popen([sys.executable, str(Path(__file__).resolve()), "--cpu-worker", str(seconds_budget), "--pin-core", str(c)],
                               stdout=subprocess.PIPE, text=True) for c in cores]
+    outs = [p.communicate()[0] for p in procs]          # every child is reaped, also when one of them failed
+    if any(p.returncode != 0 for p in procs):
+        return None
     frames, slowest = 0, 0.0
-    for p in procs:
-        out, _ = p.communicate()
-        if p.returncode != 0:
-            return None
+    for out in outs:
         n, dt = out.split()[-2:]
         frames += int(n); slowest = max(slowest, float(dt))
-    return {"value": round(frames / slowest, 1), "unit": "frames/s", "cores": len(cores), "kind": "port",
-            "sample": f"{len(cores)} independent order-7 64->64 instances, one process pinned to each of the {len(cores)} cores of this process's "
-                      f"affinity mask (os.cpu_count() = {os.cpu_count()}), {frames} blocks in {slowest:.1f} s"}
+    return frames / slowest, frames, slowest
+
+
+def cpu_baseline_allcores(seconds_budget=5.0):
+    """N independent oracle instances, one process pinned to each of N PHYSICAL cores, for N = 1, 8, 64, the cgroup's
+    CPU quota and all physical cores of the affinity mask; `value` is the best point.  (A box whose cgroup allows 16 CPUs runs 256
+    pinned processes at 1/16 speed each: round 2's 88 frames/s per core.)"""
+    aff, phys, quota = cpu_topology()
+    counts = sorted({n for n in (1, 8, 64, int(quota) if quota else 0, len(phys)) if 1 <= n <= len(phys)})
+    sweep, best = [], None
+    for n in counts:
+        r = cpu_point(phys[:n], seconds_budget)
+        if r is None:
+            continue
+        sweep.append({"processes": n, "frames_per_s": round(r[0], 1), "per_core": round(r[0] / n, 1), "blocks": r[1], "seconds": round(r[2], 2)})
+        if best is None or r[0] > best[0]:
+            best = (r[0], n)
+    if best is None:
+        return None
+    return {"value": round(best[0], 1), "unit": "frames/s", "cores": best[1], "kind": "port",
+            "physical_cores": len(phys), "logical_cpus": len(aff), "cpu_max": quota, "sweep": sweep,
+            "sample": f"independent order-7 64->64 instances, one scalar oracle process pinned to each of N physical cores (first hardware thread of every "
+                      f"(package, core) pair of the affinity mask: {len(phys)} physical cores, {len(aff)} logical CPUs, cgroup cpu.max = {quota}); "
+                      f"{seconds_budget:.0f} s per point; `value` = the best point of `sweep` (N = {best[1]})"}
 
 
 # ------------------------------------------------------------------------------------------------ multi-rank launch
@@ -132,6 +178,38 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
+def rank_proof(torch, P, world, rank, dev, rdev, backend):
+    """What the collective library saw: an all-reduce of ones on the ranks' own devices (= number of ranks that took part) and
+    every rank's device identity (name, PCI bus id / uuid), gathered.  Single process: the same fields without a collective."""
+    import torch.distributed as dist
+    if dev is not None:
+        pr = torch.cuda.get_device_properties(dev)
+        ident = {"rank": rank, "device": f"cuda:{dev.index}", "name": pr.name,
+                 "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}",
+                 "uuid": str(getattr(pr, "uuid", ""))}
+    else:
+        ident = {"rank": rank, "device": "cpu", "name": "cpu (dry run)", "pci": f"pid:{os.getpid()}", "uuid": f"pid:{os.getpid()}"}
+    if not dist.is_initialized():
+        return {"collective_backend": None, "rccl_ranks": 1, "distinct_devices": 1, "devices": [ident]}
+    ones = torch.ones(1, dtype=torch.float32, device=rdev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    return {"collective_backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_ranks": int(round(float(ones.item()))),
+            "get_world_size": dist.get_world_size(), "distinct_devices": len({(d["pci"], d["uuid"]) for d in idents}), "devices": idents}
+
+
+def per_rank_values(P, world, local_value, rdev):
+    import torch.distributed as dist
+    import torch
+    if not dist.is_initialized():
+        return [round(local_value, 1)]
+    t = torch.tensor([float(local_value)], dtype=torch.float64, device=rdev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [round(float(v.item()), 1) for v in out]
+
+
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     import torch
@@ -141,11 +219,20 @@ def run_rank(args):
     if args.dry_run:
         # launch / rendezvous / reduction path without the GPU (tests/test_dist_cpu.py): gloo, no kernels
         P.init(backend="gloo")
+        proof = rank_proof(torch, P, world, rank, None, "cpu", "gloo")
+        if proof["rccl_ranks"] != args.gpus:
+            print(f"bench.py: the collective saw {proof['rccl_ranks']} ranks, --gpus is {args.gpus}", file=sys.stderr)
+            P.finalize()
+            return 3
         P.barrier()
-        elapsed = P.max_over_ranks(0.001 * (1 + rank))
+        mine = 0.001 * (1 + rank)
+        elapsed = P.max_over_ranks(mine)
+        prv = per_rank_values(P, world, 1.0 / mine, "cpu")
         if rank == 0:
-            print(json.dumps({"metric": "audio-frames/sec (512-sample, 128-ch, 7th-order ambi_dec)", "value": None, "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_elapsed": elapsed}), flush=True)
+            line = {"metric": "audio-frames/sec (512-sample, 128-ch, 7th-order ambi_dec)", "value": None, "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "dry_run": True, "max_elapsed": elapsed, "per_rank_value": prv}
+            line.update(proof)
+            print(json.dumps(line), flush=True)
         P.finalize()
         return 0
     if torch.cuda.device_count() <= 0:          # (counting devices does not initialise the GPU)
@@ -166,6 +253,12 @@ def run_rank(args):
     else:
         P.init(backend="nccl", device=dev)      # RCCL; ranks only meet in the barriers and the MAX of the elapsed time
     rdev = "cpu" if args.share_gpu else dev     # where the timing reduction lives
+
+    proof = rank_proof(torch, P, world, rank, dev, rdev, "gloo" if args.share_gpu else "nccl")
+    if proof["rccl_ranks"] != args.gpus:
+        print(f"bench.py: the collective saw {proof['rccl_ranks']} ranks, --gpus is {args.gpus}", file=sys.stderr)
+        P.finalize()
+        return 3
 
     from spatial_audio_framework_amd import api
     from spatial_audio_framework_amd._lib import load
@@ -206,6 +299,7 @@ def run_rank(args):
         P.barrier()
         dt = time.perf_counter() - t0
         region_events_ms.setdefault(mode, ev_ms)        # the headline region runs first
+        region_events_ms.setdefault("local_s", dt)      # this rank's own time of the headline region
         L.saf_hip_profile_enable(0)
         dt = P.max_over_ranks(dt, device=rdev)
         per = {}
@@ -255,6 +349,7 @@ def run_rank(args):
 
     frames_total = world * nI * nF * args.steps
     value = frames_total / elapsed
+    prv = per_rank_values(P, world, nI * nF * args.steps / region_events_ms["local_s"], rdev)      # a straggler shows here
 
     other = None
     if world == 1 and not args.no_other_configs and not args.no_extra_paths:      # single-GPU information: not part of a scaling run
@@ -317,6 +412,8 @@ def run_rank(args):
             "timed_region_check": {"host_clock_ms": round(1e3 * elapsed, 3), "hip_events_ms": round(region_events_ms.get(args.path_mode, 0.0), 3),
                                    "note": "the K timed steps between the barriers, by the host clock (used for `value`) and by two HIP events on the library's launch stream (saf_hip_stopwatch_*)"},
         }
+        line.update(proof)
+        line["per_rank_value"] = prv
         line.update(extra)
         if other is not None:
             line["other_configs"] = other

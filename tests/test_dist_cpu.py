@@ -166,6 +166,10 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
     assert abs(line["max_elapsed"] - 0.002) < 1e-9           # the slowest rank (rank 1) defines the job time
+    # what the collective library saw (bench.py rank_proof): an all-reduce of ones = the ranks that took part, every rank's device
+    # identity gathered, and the per-rank throughput (a straggler is visible)
+    assert line["rccl_ranks"] == 2 and line["get_world_size"] == 2 and line["distinct_devices"] == 2
+    assert [d["rank"] for d in line["devices"]] == [0, 1] and line["per_rank_value"] == [1000.0, 500.0]
 
 
 def test_bench_rejects_world_size_mismatch():
