@@ -165,6 +165,69 @@ def cpu_baseline_allcores(seconds_budget=5.0):
                       f"{seconds_budget:.0f} s per point; `value` = the best point of `sweep` (N = {best[1]})"}
 
 
+# ------------------------------------------------------------------------------------------------ the unchanged signature
+def host_pointer_section(L, api):
+    """The drop-in signature itself (examples/include/ambi_dec.h:161): one 512-sample block per ambi_dec_process call, planar HOST
+    pointers in and out (pinned staging, kernels, stream sync inside the call: every sample crosses PCIe twice).  (i) one handle,
+    per-call latency; (ii) H handles driven by H host threads at once — every handle has a stream of its own inside the library."""
+    import threading
+    import numpy as np
+
+    def handle(seed):
+        d = make_decoder(api.AmbiDec)
+        for b, o in enumerate(band_orders(seed)):       # every band its own order: the general form of the block path
+            d.setDecOrder(o, b)
+        x = (np.random.default_rng(seed).random((NCH, FRAME), dtype=np.float32) * 2 - 1)
+        y = np.zeros((NCH, FRAME), np.float32)
+        px, py = api._rows(x), api._rows(y)
+        return d, x, y, px, py, (lambda: L.ambi_dec_process(d.h, px, py, NCH, NCH, FRAME))
+
+    h0 = handle(1)
+    call = h0[-1]
+    for _ in range(50):
+        call()
+    ts = []
+    for _ in range(1500):
+        t0 = time.perf_counter(); call(); ts.append(time.perf_counter() - t0)
+    ts = np.sort(np.array(ts)) * 1e6
+    one = {"median_us": round(float(ts[len(ts) // 2]), 1), "p99_us": round(float(ts[int(len(ts) * 0.99)]), 1), "min_us": round(float(ts[0]), 1),
+           "frames_per_s": round(1e6 / float(ts.mean()), 1), "block_us": round(FRAME / 48000 * 1e6, 1), "path": h0[0].lastPath()}
+    out = {"one_handle": one}
+    # H host threads, natively (tools/hostbench.c): Python threads would serialise on the interpreter lock between calls
+    so = Path(f"/tmp/libhostbench_{os.getpid()}.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", str(ROOT / "tools" / "hostbench.c"), "-o", str(so)])
+    HB = C.CDLL(str(so))
+    HB.hostbench_run.restype = C.c_double
+    HB.hostbench_run.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)] + [C.c_int] * 5
+    fnp = C.cast(L.ambi_dec_process, C.c_void_p)
+    for H in (8, 32):
+        hs = [handle(10 + i) for i in range(H)]
+        for hh in hs:
+            for _ in range(20):
+                hh[-1]()
+        M = 400
+        hv = (C.c_void_p * H)(*[hh[0].h for hh in hs])
+        iv = (C.c_void_p * H)(*[C.cast(hh[3], C.c_void_p) for hh in hs])
+        ov = (C.c_void_p * H)(*[C.cast(hh[4], C.c_void_p) for hh in hs])
+        dt = HB.hostbench_run(fnp, hv, iv, ov, H, NCH, NCH, FRAME, M)
+        assert dt > 0
+        ref = make_decoder(api.AmbiDec)             # the threaded runs must leave the right samples behind: handle 0 again, alone
+        for b, o in enumerate(band_orders(10)):
+            ref.setDecOrder(o, b)
+        yref = None
+        for _ in range(20 + M):
+            yref = ref.process(hs[0][1], NCH)
+        out[f"threads_{H}"] = {"handles": H, "host_threads": H, "calls_per_handle": M, "frames_per_s": round(H * M / dt, 1),
+                               "vs_one_handle": round(H * M / dt / one["frames_per_s"], 2), "us_per_call_per_handle": round(1e6 * dt / M, 1),
+                               "last_block_equals_single_threaded_run": bool(np.array_equal(yref, hs[0][2]))}
+        del hs
+    so.unlink()
+    out["note"] = ("ambi_dec_process(h, const float* const* in, float** out, 64, 64, 512) with host pointers, order 7 -> 64 loudspeakers, every band its own "
+                   "order; one block per call; the H-handle figures are H native threads (tools/hostbench.c) calling the C entry point, one handle each; "
+                   f"GPU_MAX_HW_QUEUES = {os.environ.get('GPU_MAX_HW_QUEUES')} (HIP maps streams onto this many hardware queues, default 4)")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ multi-rank launch
 def spawn_ranks(n, argv):
     """start n ranks of this script (one per GPU) with torch.distributed.run; this process has not touched the GPU"""
@@ -351,6 +414,11 @@ def run_rank(args):
     value = frames_total / elapsed
     prv = per_rank_values(P, world, nI * nF * args.steps / region_events_ms["local_s"], rdev)      # a straggler shows here
 
+    hostptr = None
+    if world == 1 and not args.no_extra_paths:
+        api.set_stream(None)                    # the host-pointer calls run on the handles' own streams
+        hostptr = host_pointer_section(L, api)
+        api.set_stream(torch.cuda.current_stream().cuda_stream)
     other = None
     if world == 1 and not args.no_other_configs and not args.no_extra_paths:      # single-GPU information: not part of a scaling run
         del xs, y
@@ -414,6 +482,8 @@ def run_rank(args):
         }
         line.update(proof)
         line["per_rank_value"] = prv
+        if hostptr is not None:
+            line["host_pointer"] = hostptr
         line.update(extra)
         if other is not None:
             line["other_configs"] = other

@@ -35,6 +35,7 @@
  */
 #include "saf_hip_common.h"
 #include "afstft_device.h"
+#include <mutex>
 
 namespace saf {
 
@@ -539,11 +540,15 @@ __global__ __launch_bounds__(256, 4) void afstft_synthesis_ws_kernel(SynArgs g)
 
 static float* g_dev_win[2][2] = { { nullptr, nullptr }, { nullptr, nullptr } };
 static float2* g_dev_tw = nullptr;
+static std::mutex g_tab_mutex;          /* first calls may come from several host threads at once: a table is published only when it is filled */
 
 const float* dev_window(int lowDelay, int synthesis)
 {
-    float*& d = g_dev_win[lowDelay ? 1 : 0][synthesis ? 1 : 0];
-    if (d) return d;
+    float*& slot = g_dev_win[lowDelay ? 1 : 0][synthesis ? 1 : 0];
+    if (float* q = __atomic_load_n(&slot, __ATOMIC_ACQUIRE)) return q;
+    std::lock_guard<std::mutex> lk(g_tab_mutex);
+    if (slot) return slot;
+    float* d = nullptr;
     /* afSTFTlib_init, hop 128 (afSTFT_internal.c:122-145): every 8th tap of the 10240-tap prototype,
      * reversed, times eq; the low-delay synthesis window is not reversed. */
     const float* p = table_required(lowDelay ? "afSTFT_protoFilter1024LD" : "afSTFT_protoFilter1024", 10240);
@@ -555,12 +560,15 @@ const float* dev_window(int lowDelay, int synthesis)
     }
     HIP_CHECK(hipMalloc((void**)&d, 1280 * sizeof(float)));
     HIP_CHECK(hipMemcpy(d, w.data(), 1280 * sizeof(float), hipMemcpyHostToDevice));
+    __atomic_store_n(&slot, d, __ATOMIC_RELEASE);
     return d;
 }
 
 /* [0 .. 127]: twJ[j][p] = exp(-2 pi i j p / 128), j < 8, p < 16;  [128 .. 256]: exp(-2 pi i k / 256), k <= 128 */
 const float2* dev_twiddles()
 {
+    if (float2* q = __atomic_load_n(&g_dev_tw, __ATOMIC_ACQUIRE)) return q;
+    std::lock_guard<std::mutex> lk(g_tab_mutex);
     if (g_dev_tw) return g_dev_tw;
     std::vector<float2> t(128 + 129);
     for (int j = 0; j < 8; j++)
@@ -573,9 +581,11 @@ const float2* dev_twiddles()
         t[128 + k] = make_float2((float)cos(a), (float)sin(a));
     }
     t[128 + 128] = make_float2(-1.0f, 0.0f);           /* exact: bin 128 must come out purely real */
-    HIP_CHECK(hipMalloc((void**)&g_dev_tw, t.size() * sizeof(float2)));
-    HIP_CHECK(hipMemcpy(g_dev_tw, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
-    return g_dev_tw;
+    float2* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, t.size() * sizeof(float2)));
+    HIP_CHECK(hipMemcpy(d, t.data(), t.size() * sizeof(float2), hipMemcpyHostToDevice));
+    __atomic_store_n(&g_dev_tw, d, __ATOMIC_RELEASE);
+    return d;
 }
 
 void launch_analysis(const AnaLaunch& a)

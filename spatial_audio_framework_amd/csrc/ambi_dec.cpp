@@ -73,6 +73,7 @@ struct AmbiDec {
     bool haveSTFT = false;
     unsigned long long codecEpoch = 0;     /* bumped by every initCodec; pipelines re-read the tables when it changes */
     struct DecPipeline* pipe = nullptr;    /* single-instance pipeline of ambi_dec_process */
+    hipStream_t own = nullptr;             /* ... and its stream: handles driven from different host threads do not share a queue */
     PinBuf<float> h_in, h_out;
     DevBuf<float> d_in, d_out;
 };
@@ -97,7 +98,10 @@ struct DecPipeline {
     DevBuf<float> zbuf;             /* [eqD][nInst][64][Hmax * 128] */
     DevBuf<float> zsyn[2];          /* ping-pong: [2][nInst][nSH][9][256] synthesised-frame history of z_d (SH domain) */
     DevBuf<int> zerosI;             /* [nInst][maxFrames] "band -> matrix 0" table of the time-domain GEMM */
-    DevBuf<unsigned> eqDone;        /* [nInst] equaliser workgroups finished, monotonic over the overlapped launches */
+    PinBuf<int> errPin;             /* [1] host-visible: a decode workgroup of the one-launch form gave up waiting */
+    bool deferFixup = false;        /* host-pointer caller: it synchronises anyway and then calls fixup_if_needed() instead of paying a guarded fix-up launch */
+    bool fixPending = false; BandGemmLaunch fixGemm{};
+    DevBuf<unsigned> eqDone;        /* [nInst] equaliser workgroups finished, monotonic over the publishing launches */
     DevBuf<int> eqErr;              /* [2] see DecStreamLaunch::err */
     unsigned eqDoneBase = 0;
     int lastOverlap = 0;            /* 1: the last call ran the decode kernel beside the equaliser kernel */
@@ -134,6 +138,11 @@ struct DecPipeline {
     };
     std::vector<Shadow> shadow;
     PinBuf<float> stageA; PinBuf<int> stageI; PinBuf<float> stageS;
+    /* Staging: every instance has its own slot in the pinned blocks of the small tables, so the uploads of a call are queued
+     * without a synchronisation between instances; the call that next has something to upload first waits for these copies. */
+    bool stagePending = false;
+    std::vector<char> afragDirty;   /* per instance: the 14 effective matrices of the transform path / binaural fold are stale */
+    void begin_staging() { if (stagePending) { HIP_CHECK(hipStreamSynchronize(stream())); stagePending = false; } }
 
     void create(AmbiDec* const* handles, int n, int maxFrames_)
     {
@@ -166,8 +175,8 @@ struct DecPipeline {
         chScale.alloc((size_t)nInst * SAF_MAXCH);
         chMap.alloc((size_t)nInst * SAF_MAXCH);
         shadow.assign(nInst, Shadow());
-        eqDirty.assign(nInst, 1); eqTwo.assign(nInst, 0); eqTwoEpoch.assign(nInst, ~0ull);
-        stageA.ensure((size_t)NMAT * 64 * 64); stageI.ensure(SAF_NBANDS + SAF_MAXCH); stageS.ensure(SAF_MAXCH);
+        eqDirty.assign(nInst, 1); eqTwo.assign(nInst, 0); eqTwoEpoch.assign(nInst, ~0ull); afragDirty.assign(nInst, 1);
+        stageA.ensure((size_t)NMAT * 64 * 64); stageI.ensure((size_t)nInst * (SAF_NBANDS + SAF_MAXCH)); stageS.ensure((size_t)nInst * SAF_MAXCH);
     }
 
     /* spectra of the transform path (4.5 GB each at 256 instances x 64 blocks): allocated when that path first runs */
@@ -189,12 +198,23 @@ struct DecPipeline {
             std::fill(eqDirty.begin(), eqDirty.end(), 1);
             if (!eqUni.p) {
                 eqUni.alloc((size_t)nInst * SAF_MAXCH); Mfrag.alloc((size_t)nInst * 2 * 64 * 64); zerosI.alloc((size_t)nInst * maxFrames);
-                stageG.ensure((size_t)2 * SAF_MAXCH * 136); stageM.ensure((size_t)2 * 64 * 64); stageU.ensure(SAF_MAXCH);
+                stageG.ensure((size_t)nInst * 2 * SAF_MAXCH * 136); stageM.ensure((size_t)nInst * 2 * 64 * 64); stageU.ensure((size_t)nInst * SAF_MAXCH);
                 for (int i = 0; i < 2; i++) zsyn[i].alloc((size_t)2 * nInst * nSH * SAF_SYN_HIST * 256);
                 eqDone.alloc(nInst); eqErr.alloc(2); eqDoneBase = 0;
+                errPin.ensure(1); errPin.p[0] = 0;
             }
             (void)oldD;     /* zsyn holds both outputs from the start: a pipeline that goes from one dense matrix to two keeps z_0's history, z_1's starts from zero */
         }
+    }
+    /* after the caller's synchronisation: the decode of the last one-launch call, should one of its workgroups have given up */
+    void fixup_if_needed()
+    {
+        if (!fixPending) return;
+        fixPending = false;
+        if (__atomic_load_n(errPin.p, __ATOMIC_ACQUIRE) == 0) return;
+        fixGemm.runFlag = nullptr;
+        launch_band_gemm(fixGemm);
+        HIP_CHECK(hipStreamSynchronize(stream()));
     }
     /* afSTFT_clearBuffers for the whole pipeline (ambi_dec.c:218,225) */
     void clear_state()
@@ -239,11 +259,12 @@ struct DecPipeline {
         ensure_eq_buffers(two_dense_matrices() ? 2 : 1);
         const bool force = mode == 2;
         if (force != mode2Shadow) { std::fill(eqDirty.begin(), eqDirty.end(), 1); mode2Shadow = force; }
+        bool began = false;
         for (int i = 0; i < nInst; i++) {
             if (!eqDirty[i]) continue;
             AmbiDec* p = inst[i];
             const Shadow& s = shadow[i];
-            HIP_CHECK(hipStreamSynchronize(stream()));       /* staging buffers may still be in flight */
+            if (!began) { begin_staging(); began = true; }
             /* w_{d,n}[k] = M_norm_{d,n} * (max-rE ? a_n[k] : 1) for k < (n+1)^2 (ambi_dec.c:524-539) */
             float wtab[NUM_DECODERS][SAF_MAX_ORDER][SAF_MAXCH];
             memset(wtab, 0, sizeof(wtab));
@@ -253,8 +274,9 @@ struct DecPipeline {
                     const float msc = p->M_norm[d][n - 1][s.eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
                     for (int k = 0; k < ORDER2NSH(n); k++) wtab[d][n - 1][k] = (s.rE[d] ? a_n[k] : 1.0f) * msc;
                 }
-            float* G = stageG.p; int* U = stageU.p;
-            memset(G, 0, sizeof(float) * (size_t)eqD * SAF_MAXCH * 136);
+            const size_t nG = (size_t)eqD * SAF_MAXCH * 136;
+            float* G = stageG.p + (size_t)i * nG; int* U = stageU.p + (size_t)i * SAF_MAXCH;
+            memset(G, 0, sizeof(float) * nG);
             for (int ch = 0; ch < SAF_MAXCH; ch++) {
                 bool uniform = true;
                 for (int band = 0; band < SAF_NBANDS; band++) {
@@ -268,20 +290,52 @@ struct DecPipeline {
                         uniform = uniform && G[((size_t)d * SAF_MAXCH + ch) * 136 + band] == G[((size_t)d * SAF_MAXCH + ch) * 136];
                 U[ch] = uniform && !force ? 1 : 0;
             }
-            HIP_CHECK(hipMemcpyAsync(eqGains.p + (size_t)i * eqD * SAF_MAXCH * 136, G, sizeof(float) * (size_t)eqD * SAF_MAXCH * 136, hipMemcpyHostToDevice, stream()));
+            HIP_CHECK(hipMemcpyAsync(eqGains.p + (size_t)i * nG, G, sizeof(float) * nG, hipMemcpyHostToDevice, stream()));
             HIP_CHECK(hipMemcpyAsync(eqUni.p + (size_t)i * SAF_MAXCH, U, sizeof(int) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
             /* the dense decoders: the order-N matrices without max-rE / normalisation (ambi_dec.c:283-288), zero-padded */
             std::vector<float> A(64 * 64);
             const int nSHo = ORDER2NSH(p->masterOrder);
+            float* Ms = stageM.p + (size_t)i * 2 * 64 * 64;
             for (int d = 0; d < NUM_DECODERS; d++) {
                 std::fill(A.begin(), A.end(), 0.0f);
                 const std::vector<float>& M = p->M_dec[d][p->masterOrder - 1];
                 for (int l = 0; l < p->nLoudpkrs; l++) for (int k = 0; k < nSHo; k++) A[l * 64 + k] = M[(size_t)l * nSHo + k];
-                pack_A(A.data(), stageM.p + (size_t)d * 64 * 64);
+                pack_A(A.data(), Ms + (size_t)d * 64 * 64);
             }
-            HIP_CHECK(hipMemcpyAsync(Mfrag.p + (size_t)i * 2 * 64 * 64, stageM.p, sizeof(float) * 2 * 64 * 64, hipMemcpyHostToDevice, stream()));
-            HIP_CHECK(hipStreamSynchronize(stream()));
+            HIP_CHECK(hipMemcpyAsync(Mfrag.p + (size_t)i * 2 * 64 * 64, Ms, sizeof(float) * 2 * 64 * 64, hipMemcpyHostToDevice, stream()));
             eqDirty[i] = 0;
+        }
+        if (began) stagePending = true;
+    }
+
+    /* the 14 effective matrices M_norm * (maxrE ? M_dec_maxrE : M_dec), zero-padded 64 x 64 (ambi_dec.c:524-539), of the
+     * instances whose codec or weighting changed: only the transform path and the binaural fold read them */
+    void upload_afrag()
+    {
+        for (int i = 0; i < nInst; i++) {
+            if (!afragDirty[i]) continue;
+            AmbiDec* p = inst[i];
+            const Shadow& s = shadow[i];
+            HIP_CHECK(hipStreamSynchronize(stream()));       /* one staging block for all instances: rare path */
+            stagePending = false;
+            std::vector<float> A(64 * 64);
+            for (int d = 0; d < NUM_DECODERS; d++)
+                for (int n = 1; n <= SAF_MAX_ORDER; n++) {
+                    std::fill(A.begin(), A.end(), 0.0f);
+                    if (n <= p->masterOrder) {
+                        const int nSHo = ORDER2NSH(n);
+                        const std::vector<float>& M = s.rE[d] ? p->M_dec_maxrE[d][n - 1] : p->M_dec[d][n - 1];
+                        const float sc = p->M_norm[d][n - 1][s.eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
+                        for (int l = 0; l < p->nLoudpkrs; l++)
+                            for (int k = 0; k < nSHo; k++) A[l * 64 + k] = M[(size_t)l * nSHo + k] * sc;
+                    }
+                    pack_A(A.data(), stageA.p + (size_t)(d * SAF_MAX_ORDER + n - 1) * 64 * 64);
+                    if (bin) memcpy(stageArow.p + (size_t)(d * SAF_MAX_ORDER + n - 1) * 64 * 64, A.data(), sizeof(float) * 64 * 64);
+                }
+            HIP_CHECK(hipMemcpyAsync(Afrag.p + (size_t)i * NMAT * 64 * 64, stageA.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream()));
+            if (bin) { HIP_CHECK(hipMemcpyAsync(Arow.p + (size_t)i * NMAT * 64 * 64, stageArow.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream())); foldDirty = true; }
+            HIP_CHECK(hipStreamSynchronize(stream()));
+            afragDirty[i] = 0;
         }
     }
 
@@ -289,34 +343,17 @@ struct DecPipeline {
      * snapshotted at the start of a block like ambi_dec.c:479-488) */
     void refresh()
     {
+        bool began = false;
+        auto stage = [&]() { if (!began) { begin_staging(); began = true; } };
         for (int i = 0; i < nInst; i++) {
             AmbiDec* p = inst[i];
             Shadow& s = shadow[i];
             const int rE[2] = { p->rE_WEIGHT[0], p->rE_WEIGHT[1] }, eq[2] = { p->diffEQmode[0], p->diffEQmode[1] };
             if (s.epoch != p->codecEpoch || s.rE[0] != rE[0] || s.rE[1] != rE[1] || s.eq[0] != eq[0] || s.eq[1] != eq[1]) {
-                /* effective matrix of (decoder d, order n): M_norm * (maxrE ? M_dec_maxrE : M_dec), zero-padded 64x64
-                 * (ambi_dec.c:524-539) */
-                HIP_CHECK(hipStreamSynchronize(stream()));       /* staging buffer may still be in flight */
-                std::vector<float> A(64 * 64);
-                for (int d = 0; d < NUM_DECODERS; d++)
-                    for (int n = 1; n <= SAF_MAX_ORDER; n++) {
-                        std::fill(A.begin(), A.end(), 0.0f);
-                        if (n <= p->masterOrder) {
-                            const int nSHo = ORDER2NSH(n);
-                            const std::vector<float>& M = rE[d] ? p->M_dec_maxrE[d][n - 1] : p->M_dec[d][n - 1];
-                            const float sc = p->M_norm[d][n - 1][eq[d] == AMPLITUDE_PRESERVING ? 0 : 1];
-                            for (int l = 0; l < p->nLoudpkrs; l++)
-                                for (int k = 0; k < nSHo; k++) A[l * 64 + k] = M[(size_t)l * nSHo + k] * sc;
-                        }
-                        pack_A(A.data(), stageA.p + (size_t)(d * SAF_MAX_ORDER + n - 1) * 64 * 64);
-                        if (bin) memcpy(stageArow.p + (size_t)(d * SAF_MAX_ORDER + n - 1) * 64 * 64, A.data(), sizeof(float) * 64 * 64);
-                    }
-                HIP_CHECK(hipMemcpyAsync(Afrag.p + (size_t)i * NMAT * 64 * 64, stageA.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream()));
-                if (bin) { HIP_CHECK(hipMemcpyAsync(Arow.p + (size_t)i * NMAT * 64 * 64, stageArow.p, sizeof(float) * NMAT * 64 * 64, hipMemcpyHostToDevice, stream())); foldDirty = true; }
-                HIP_CHECK(hipStreamSynchronize(stream()));
                 if (s.epoch != ~0ull && s.epoch != p->codecEpoch) clear_instance(i);      /* re-initialised codec: ambi_dec_initCodec clears the filterbank (ambi_dec.c:218,225) */
                 s.epoch = p->codecEpoch; s.rE[0] = rE[0]; s.rE[1] = rE[1]; s.eq[0] = eq[0]; s.eq[1] = eq[1];
-                s.b2mValid = false; s.norm = -1; eqDirty[i] = 1;
+                s.b2mValid = false; s.norm = -1; eqDirty[i] = 1; afragDirty[i] = 1;
+                if (bin) foldDirty = true;
             }
             int b2m[SAF_NBANDS];
             for (int band = 0; band < SAF_NBANDS; band++) {
@@ -325,17 +362,17 @@ struct DecPipeline {
                 const int decIdx = p->freqVector[band] < p->transitionFreq ? 0 : 1;      /* ambi_dec.c:519-523 */
                 b2m[band] = decIdx * SAF_MAX_ORDER + ob - 1;
             }
+            int* slotI = stageI.p + (size_t)i * (SAF_NBANDS + SAF_MAXCH);
             if (!s.b2mValid || memcmp(b2m, s.b2m, sizeof(b2m)) != 0) {
-                HIP_CHECK(hipStreamSynchronize(stream()));
-                memcpy(stageI.p, b2m, sizeof(b2m));
-                HIP_CHECK(hipMemcpyAsync(band2mat.p + (size_t)i * SAF_NBANDS, stageI.p, sizeof(b2m), hipMemcpyHostToDevice, stream()));
-                HIP_CHECK(hipStreamSynchronize(stream()));
+                stage();
+                memcpy(slotI, b2m, sizeof(b2m));
+                HIP_CHECK(hipMemcpyAsync(band2mat.p + (size_t)i * SAF_NBANDS, slotI, sizeof(b2m), hipMemcpyHostToDevice, stream()));
                 memcpy(s.b2m, b2m, sizeof(b2m)); s.b2mValid = true; foldDirty = true; eqDirty[i] = 1;
             }
             if (s.norm != (int)p->norm || s.chOrd != (int)p->chOrdering) {
                 /* input conventions -> ACN/N3D (ambi_dec.c:500-511, saf_hoa.c:40-116) as a gather map + row scale */
-                HIP_CHECK(hipStreamSynchronize(stream()));
-                int* map = stageI.p; float* sc = stageS.p;
+                stage();
+                int* map = slotI + SAF_NBANDS; float* sc = stageS.p + (size_t)i * SAF_MAXCH;
                 for (int ch = 0; ch < SAF_MAXCH; ch++) { map[ch] = ch; sc[ch] = 1.0f; }
                 if (p->chOrdering == CH_FUMA) {
                     /* FuMa WXYZ -> ACN WYZX, first order only; higher channels are zeroed (saf_hoa.c:58-69) */
@@ -351,10 +388,10 @@ struct DecPipeline {
                 }
                 HIP_CHECK(hipMemcpyAsync(chMap.p + (size_t)i * SAF_MAXCH, map, sizeof(int) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
                 HIP_CHECK(hipMemcpyAsync(chScale.p + (size_t)i * SAF_MAXCH, sc, sizeof(float) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
-                HIP_CHECK(hipStreamSynchronize(stream()));
                 s.norm = (int)p->norm; s.chOrd = (int)p->chOrdering;
             }
         }
+        if (began) stagePending = true;
     }
 
     /* interpolated HRTFs of the loudspeakers whose direction changed (ambi_dec.c:549-553, ambi_dec_interpHRTFs =
@@ -393,6 +430,7 @@ struct DecPipeline {
         if (nFrames > maxFrames) SAF_FATAL("ambi_dec batch: nFrames %d exceeds the maxFramesPerCall %d given at creation", nFrames, maxFrames);
         refresh();
         if (bin) {
+            upload_afrag();
             refresh_hrtfs();
             if (foldDirty) {
                 BinFoldLaunch f{};
@@ -433,7 +471,26 @@ struct DecPipeline {
             ds.Y = d_out; ds.y_inst = out_inst; ds.y_frame = out_frame; ds.y_row = out_ch;
             ds.Mfrag = Mfrag.p; ds.m_inst = 2 * 64 * 64; ds.nRowsY = nLS; ds.F = F; ds.nFrames = nFrames;
             const bool overlap = g_ambi_dec_overlap != 0 && (g_ambi_dec_overlap == 2 || ((long long)nInst * nSH >= 3072 && H >= 32)) &&
-                                 dec_stream_supported(ds);
+                                 !on_private_stream() && dec_stream_supported(ds);      /* (one side stream per process: not from a handle's own stream) */
+            /* Small launches (the one-block host-pointer call is bound by launches, not by the chip): equaliser and decode in ONE
+             * launch — the decode workgroups ride behind the channel workgroups and wait on the instance's counter. */
+            static const int fuseSmall = []() { const char* v = getenv("SAF_HIP_AMBI_DEC_ONE_LAUNCH"); return v ? atoi(v) : 1; }();
+            if (fuseSmall && !overlap) {
+                EqDecodeTail t{};
+                t.Y = d_out; t.y_inst = out_inst; t.y_frame = out_frame; t.y_row = out_ch; t.Mfrag = Mfrag.p; t.m_inst = 2 * 64 * 64;
+                t.nRowsY = nLS; t.F = F; t.nFrames = nFrames; t.err = errPin.p;
+                const int units = nFrames * (F / 128);
+                t.G = (units + 7) / 8;                                  /* at most 8 decode workgroups per instance */
+                if (launch_eq_decode(q, t, eqDone.p, eqDoneBase + (unsigned)nSH)) {
+                    eqDoneBase += (unsigned)nSH;
+                    st.anaPar ^= 1; zsynPar ^= 1;
+                    gn.runFlag = errPin.p;
+                    if (deferFixup) { fixGemm = gn; fixPending = true; }
+                    else launch_band_gemm(gn);                          /* leaves at once unless a decode workgroup gave up */
+                    synDomain = DOM_SH; lastPath = 1; lastOverlap = 0;
+                    return;
+                }
+            }
             if (overlap) {
                 ds.done = eqDone.p; ds.target = eqDoneBase + (unsigned)nSH; ds.err = eqErr.p;
                 eqDoneBase += (unsigned)nSH;
@@ -450,6 +507,7 @@ struct DecPipeline {
             return;
         }
         ensure_transform_buffers();
+        upload_afrag();
         if (synDomain == DOM_SH) {
             /* the overlap-add history of the equaliser path, taken to the loudspeaker domain: st.syn = sum_d M_d zsyn_d */
             const long long fr = (long long)SAF_SYN_HIST * 256;
@@ -559,7 +617,11 @@ void ambi_dec_destroy(void** const phAmbi)
     AmbiDec* p = (AmbiDec*)*phAmbi;
     if (!p) return;
     while (p->codecStatus == CODEC_STATUS_INITIALISING || p->procStatus == PROC_STATUS_ONGOING) sleep_ms(10);
-    if (p->pipe) { HIP_CHECK(hipStreamSynchronize(stream())); delete p->pipe; }
+    {
+        StreamScope onOwn(p->own);
+        if (p->pipe) { HIP_CHECK(hipStreamSynchronize(stream())); delete p->pipe; }
+    }
+    if (p->own) HIP_CHECK(hipStreamDestroy(p->own));
     delete p;
     *phAmbi = nullptr;
 }
@@ -592,7 +654,7 @@ void ambi_dec_initCodec(void* const hAmbi)
     const int max_nSH = ORDER2NSH(masterOrder);
     int nLS = p->new_nLoudpkrs;
     /* (re)create the filterbank state: channel change + clearBuffers == fresh zero state (ambi_dec.c:213-226) */
-    if (p->pipe) { HIP_CHECK(hipStreamSynchronize(stream())); delete p->pipe; p->pipe = nullptr; }
+    if (p->pipe) { StreamScope onOwn(p->own); HIP_CHECK(hipStreamSynchronize(stream())); delete p->pipe; p->pipe = nullptr; }
     p->haveSTFT = true;
     p->binauraliseLS = p->new_binauraliseLS;
     p->nLoudpkrs = nLS;
@@ -681,10 +743,16 @@ void ambi_dec_process(void* const hAmbi, const float* const* inputs, float** con
     if (nSamples == F && p->codecStatus == CODEC_STATUS_INITIALISED) {
         p->procStatus = PROC_STATUS_ONGOING;
         const int nSH = ORDER2NSH(p->masterOrder), nLS = p->nLoudpkrs;
+        /* every handle works on a stream of its own: the call is synchronous for its caller (it ends with a stream sync), and
+         * handles driven from different host threads (SURVEY 8b "Threading": one call at a time per handle) run side by side
+         * instead of queueing on the process-wide stream */
+        if (!p->own) p->own = new_stream();
+        StreamScope onOwn(p->own);
         if (!p->pipe) {
             p->pipe = new DecPipeline();
             AmbiDec* self = p;
             p->pipe->create(&self, 1, 1);
+            p->pipe->deferFixup = true;
             p->h_in.ensure((size_t)SAF_MAXCH * F); p->h_out.ensure((size_t)SAF_MAXCH * F);
             p->d_in.alloc((size_t)SAF_MAXCH * F, false); p->d_out.alloc((size_t)SAF_MAXCH * F, false);
         }
@@ -705,7 +773,8 @@ void ambi_dec_process(void* const hAmbi, const float* const* inputs, float** con
             p->pipe->process(p->d_in.p, 0, 0, F, nRows, p->d_out.p, 0, 0, F, 1);
             HIP_CHECK(hipMemcpyAsync(p->h_out.p, p->d_out.p, sizeof(float) * (size_t)nOutCh * F, hipMemcpyDeviceToHost, stream()));
         }
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        wait_stream(stream());
+        p->pipe->fixup_if_needed();
         int ch;
         for (ch = 0; ch < (nOutCh < nOutputs ? nOutCh : nOutputs); ch++) memcpy(outputs[ch], p->h_out.p + (size_t)ch * F, sizeof(float) * F);
         for (; ch < nOutputs; ch++) memset(outputs[ch], 0, sizeof(float) * F);

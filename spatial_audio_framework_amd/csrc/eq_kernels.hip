@@ -37,6 +37,7 @@
  */
 #include "saf_hip_common.h"
 #include "afstft_device.h"
+#include "mfma_tile.h"
 
 namespace saf {
 
@@ -54,7 +55,8 @@ namespace saf {
 #endif
 
 struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; int chunk; unsigned long long* stamps;
-                unsigned* done; int prio; };      /* PUBLISH launches: [nInst] counters of finished workgroups (see the end of the kernel) */
+                unsigned* done; int prio;         /* publishing launches: [nInst] counters of finished workgroups (see the end of the kernel) */
+                EqDecodeTail dec; unsigned target; };   /* MODE 2: the decode blocks behind the channel blocks of every instance */
 #ifdef EQ_STAMPS        /* diagnostic build only: cycles per phase of every 64th workgroup (tools/eq_stamps.py) */
 #define STAMP(i) do { if (stampOn && lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += t_ - stampT; stampT = t_; } } while (0)
 #else
@@ -70,8 +72,74 @@ struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* t
 #else
 #define EQ_NO_DS_PAIRING
 #endif
-template <int D, bool PUBLISH>
-__global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING void afstft_eq_kernel(EqArgs g)
+/* MODE 2, small launches (one block of one handle: the host-pointer ambi_dec_process): the time-domain decode  out = sum_d M_d z_d
+ * rides in the SAME launch, as extra workgroups (blockIdx.x >= nCh) behind the channel workgroups of their instance: they
+ * wait until the instance's counter says that all its channels have published their z, then multiply (one 64 x 128 tile per
+ * unit, half a tile's operands in flight at a time: latency is what matters here, not bandwidth).  One launch per call instead of
+ * two: the host-pointer path is bound by launches (profiles/r03_host_pointer.txt).  The launcher only uses this mode when every
+ * workgroup of the launch is resident at once, and a poll that is not answered gives up and reports through err[0]. */
+template <int D>
+__device__ __forceinline__ void decode_tail(const EqLaunch& e, const EqDecodeTail& r, const unsigned* done, unsigned target,
+                                            float* sA0, float* sA1, int* s_ok, int inst, int gi)
+{
+    const int tid = threadIdx.x, lane = tid & 63, rt = tid >> 6, kh = lane >> 5;
+    {
+        const float4* Ag = reinterpret_cast<const float4*>(r.Mfrag + (long long)inst * r.m_inst);
+#pragma unroll
+        for (int i = 0; i < 8; i++) reinterpret_cast<float4*>(sA0)[tid + 128 * i] = Ag[tid + 128 * i];
+        if (D > 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) reinterpret_cast<float4*>(sA1)[tid + 128 * i] = Ag[1024 + tid + 128 * i];
+        }
+    }
+    if (tid == 0) {
+        int ok = 0;
+        for (int it = 0; it < 2000000; it++) {          /* bounded: ~1 s */
+            const unsigned v = __hip_atomic_load(done + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(v - target) >= 0) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (ok) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else
+            __hip_atomic_store(r.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *s_ok = ok;
+    }
+    __syncthreads();
+    if (!*s_ok) return;
+    const int nColTiles = r.F / 128, units = r.nFrames * nColTiles;
+    const int u0 = gi * r.G, u1 = min(u0 + r.G, units);
+    const int lastRow = e.nCh - 1;
+    for (int u = u0; u < u1; u++) {
+        const int fr = u / nColTiles, ct = u - fr * nColTiles;
+        const int col = ct * 128 + 4 * (lane & 31);
+        Tile128 t;
+        tile_zero(t);
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const float* Z = e.z + (long long)d * e.z_d + (long long)inst * e.z_inst + (long long)fr * r.F + col;
+            const float* As = (d == 0 ? sA0 : sA1) + rt * 2048 + lane;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                float4 b[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) b[i] = *reinterpret_cast<const float4*>(Z + (long long)min(2 * (16 * half + i) + kh, lastRow) * e.z_ch);
+#pragma unroll
+                for (int i = 0; i < 16; i++) tile_step(t, As[(16 * half + i) * 64], b[i]);
+            }
+        }
+        float* Y = r.Y + (long long)inst * r.y_inst + (long long)fr * r.y_frame + col;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int row = rt * 32 + tile_row(q, lane);
+            if (row < r.nRowsY) *reinterpret_cast<float4*>(Y + (long long)row * r.y_row) = make_float4(t.c[0][q], t.c[1][q], t.c[2][q], t.c[3][q]);
+        }
+    }
+}
+
+template <int D, int MODE>
+__global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING void afstft_eq_kernel(EqArgs g)      /* (MODE 2: small launches, occupancy does not matter) */
 {
     __shared__ __attribute__((aligned(16))) float s_ring[ERING * SLOT];
     __shared__ __attribute__((aligned(16))) float s_out1[D > 1 ? SUB * SLOT : 4];      /* frames of the second output */
@@ -91,7 +159,13 @@ __global__ __launch_bounds__(128, D == 1 ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING voi
 
     const EqLaunch& e = g.e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr bool PUBLISH = MODE != 0;
     const int ch = blockIdx.x, inst = blockIdx.y;
+    if (MODE == 2) {
+        __shared__ int s_ok;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) __hip_atomic_store(g.dec.err, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int)blockIdx.x >= e.nCh) { decode_tail<D>(e, g.dec, g.done, g.target, s_ring, s_out1, &s_ok, inst, (int)blockIdx.x - e.nCh); return; }
+    }
     const int T = e.hopsPerFrame;
     /* Beside the decode kernel (launch_dec_stream) the waves of this kernel share their SIMDs with MFMA waves that were
      * dispatched earlier: arbitration is by priority, then age, so at equal priority the MFMA wave takes every issue slot it
@@ -503,16 +577,46 @@ void launch_eq(const EqLaunch& e, unsigned* done)
     }
     const dim3 grid(e.nCh, e.nInst, (e.H + g.chunk - 1) / g.chunk);
     KernelTimer kt("afstft_eq");
-    g.done = done;
+    g.done = done; g.target = 0; g.dec = EqDecodeTail{};
     { static const int p = []() { const char* v = getenv("SAF_HIP_EQ_PRIO"); return v ? atoi(v) : -1; }(); g.prio = p >= 0 ? p : (done != nullptr); }
     if (done) {
-        if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, true>), grid, dim3(128), 0, stream(), g);
-        else          hipLaunchKernelGGL((afstft_eq_kernel<2, true>), grid, dim3(128), 0, stream(), g);
+        if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, 1>), grid, dim3(128), 0, stream(), g);
+        else          hipLaunchKernelGGL((afstft_eq_kernel<2, 1>), grid, dim3(128), 0, stream(), g);
     } else {
-        if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, false>), grid, dim3(128), 0, stream(), g);
-        else          hipLaunchKernelGGL((afstft_eq_kernel<2, false>), grid, dim3(128), 0, stream(), g);
+        if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, 0>), grid, dim3(128), 0, stream(), g);
+        else          hipLaunchKernelGGL((afstft_eq_kernel<2, 0>), grid, dim3(128), 0, stream(), g);
     }
     HIP_CHECK(hipGetLastError());
+}
+
+bool launch_eq_decode(const EqLaunch& e, const EqDecodeTail& d, unsigned* done, unsigned target)
+{
+    if (e.H <= 0 || e.nCh <= 0 || e.nInst <= 0) return true;
+    if (e.D != 1 && e.D != 2) SAF_FATAL("filterbank equaliser: D must be 1 or 2");
+    if (d.F % 128 != 0 || d.nFrames * (d.F / SAF_HOP) != e.H || d.G < 1) return false;
+    if (((d.y_inst | d.y_frame | d.y_row | e.z_inst | e.z_ch | e.z_d | d.m_inst) & 3) || ((uintptr_t)d.Y & 15) || ((uintptr_t)e.z & 15)) return false;
+    const int units = d.nFrames * (d.F / 128), nDec = (units + d.G - 1) / d.G;
+    /* every workgroup of the launch must be resident at once (6 per compute unit on 256 compute units, with a margin for other
+     * streams' launches): a waiting decode workgroup then never keeps a channel workgroup of its launch off the chip */
+    if ((long long)e.nInst * (e.nCh + nDec) > 768) return false;
+    const long long chSpan = (long long)(e.nChIn > 0 ? e.nChIn : 1) * e.in_ch;
+    const long long hopSpan = (long long)((e.H + e.hopsPerFrame - 1) / e.hopsPerFrame) * e.in_frame + (long long)e.hopsPerFrame * SAF_HOP;
+    if (e.in_ch < 0 || e.in_frame < 0 || e.H >= (1 << 22) || (chSpan + hopSpan) * 4 >= (1ll << 32))
+        SAF_FATAL("filterbank equaliser: one call spans more than 4 GiB of one instance's input, 2^22 hops or uses negative strides: split the call");
+    EqArgs g;
+    g.e = e;
+    g.win = dev_window(0, 0);
+    g.twJ = dev_twiddles();
+    g.tw256 = g.twJ + 128;
+    g.stamps = nullptr;
+    g.chunk = e.H;
+    g.done = done; g.target = target; g.dec = d; g.prio = 0;
+    const dim3 grid(e.nCh + nDec, e.nInst, 1);
+    KernelTimer kt("afstft_eq_decode");
+    if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, 2>), grid, dim3(128), 0, stream(), g);
+    else          hipLaunchKernelGGL((afstft_eq_kernel<2, 2>), grid, dim3(128), 0, stream(), g);
+    HIP_CHECK(hipGetLastError());
+    return true;
 }
 
 }  // namespace saf

@@ -6,6 +6,7 @@
 #include "saf_hip_common.h"
 #include "../../include/saf_hip.h"
 #include <mutex>
+#include <sched.h>
 
 namespace saf {
 
@@ -33,8 +34,38 @@ void ensure_device()
     ensure_device_locked();
 }
 
+/* A calling thread may redirect the library's launches to a stream of its own for the duration of a call (StreamScope): the
+ * host-pointer ambi_dec_process gives every handle its own stream, so that N host threads driving N handles do not queue behind
+ * one another on the process-wide stream. */
+static thread_local hipStream_t t_stream = nullptr;
+StreamScope::StreamScope(hipStream_t s) : prev(t_stream) { if (s) t_stream = s; }
+StreamScope::~StreamScope() { t_stream = prev; }
+bool on_private_stream() { return t_stream != nullptr; }
+/* End of a host-pointer call: wait for the handle's stream.  hipStreamSynchronize spins; with more calling threads than the
+ * process may use CPUs (a 16-CPU cgroup driving 32 handles) the spinning threads take the CPUs from the ones that have work to
+ * launch.  So: poll for the time a lone call needs, then give the CPU away between polls. */
+void wait_stream(hipStream_t s)
+{
+    for (int i = 0; i < 4000; i++) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) HIP_CHECK(e);
+        if (i >= 64) sched_yield();
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+hipStream_t new_stream()
+{
+    ensure_device();
+    hipStream_t ns = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+    return ns;
+}
+
 hipStream_t stream()
 {
+    if (t_stream) return t_stream;
     /* fast path: the pointer is written once under the lock (and by set_stream, which callers do not race with launches) */
     hipStream_t s = __atomic_load_n(&g_stream, __ATOMIC_ACQUIRE);
     if (s) return s;

@@ -50,6 +50,16 @@ hipStream_t side_stream();            /* second stream: kernels that run beside 
 void        side_fork();              /* work enqueued on side_stream() after this call starts after what is on stream() now */
 void        side_join();              /* work enqueued on stream() after this call starts after what is on side_stream() now */
 void        set_stream(hipStream_t);  /* adopt a caller's stream (e.g. torch's current stream) */
+hipStream_t new_stream();             /* a non-blocking stream of the library's device */
+void        wait_stream(hipStream_t); /* wait for a stream from a host-pointer call: polls, yields the CPU between polls when it takes long */
+bool        on_private_stream();      /* this thread is inside a StreamScope */
+struct StreamScope {                  /* RAII: stream() of the calling thread returns `s` until the scope ends (s == nullptr: no change) */
+    explicit StreamScope(hipStream_t s);
+    ~StreamScope();
+    hipStream_t prev;
+    StreamScope(const StreamScope&) = delete;
+    StreamScope& operator=(const StreamScope&) = delete;
+};
 void        ensure_device();          /* aborts with a clear message when no GPU is usable */
 
 /* ---- host-pointer entry points (runtime.cpp) ---- */
@@ -173,6 +183,17 @@ struct EqLaunch {
 /* done != nullptr: every workgroup (one per channel and instance, no time chunks) publishes its z and adds 1 to done[inst] when
  * it has finished — the decode kernel of launch_dec_stream consumes the instances as they complete */
 void launch_eq(const EqLaunch& e, unsigned* done = nullptr);
+
+/* Small launches (the one-block host-pointer call): equaliser AND decode in ONE launch — the decode workgroups ride behind the
+ * channel workgroups of their instance and wait on done[inst] (eq_kernels.hip, MODE 2).  Returns false when the launch is too
+ * large for every workgroup to be resident at once or the shapes do not fit (then: launch_eq + launch_band_gemm). */
+struct EqDecodeTail {
+    float* Y; long long y_inst, y_frame, y_row;   /* out[inst*y_inst + frame*y_frame + row*y_row + n], n < F */
+    const float* Mfrag; long long m_inst;         /* dense decoder(s) of an instance in MFMA fragment order: [D][2][32][64] */
+    int nRowsY, F, nFrames, G;                    /* G: 128-column units per decode workgroup */
+    int* err;                                     /* [1] host-visible: set when a decode workgroup gave up waiting (the caller then runs the GEMM) */
+};
+bool launch_eq_decode(const EqLaunch& e, const EqDecodeTail& d, unsigned* done, unsigned target);
 
 /* ---- the time-domain decode  out = sum_d M_d z_d  running BESIDE the equaliser kernel (gemm_kernels.hip) ----
  * A persistent grid of register-lean MFMA workgroups on the library's second stream: workgroup p takes the work items

@@ -104,6 +104,44 @@ def test_initCodec_on_second_thread_while_processing(saf):
     assert np.isfinite(y).all() and np.abs(y[:, 13 * F:]).max() > 1e-3
 
 
+def test_eight_handles_on_eight_threads_match_the_oracle(saf, orc):
+    """H handles driven by H host threads at once through the unchanged ambi_dec_process (host pointers): every handle works on a
+    stream of its own (ambi_dec.cpp), nothing is shared between them but read-only tables — each thread's output equals the
+    oracle's, and equals what the same handle configuration gives when it runs alone."""
+    F, order, H, nB = 256, 5, 8, 14
+    cfg = [(1 + i % 4, 1 + (i // 2) % 4, 1 + i % 2) for i in range(H)]
+
+    def mk(cls, i):
+        d = cls(F)
+        d.setNormType(cfg[i][2]); d.setChOrder(1); d.setMasterDecOrder(order); d.setOutputConfigPreset(28)
+        d.setDecMethod(0, cfg[i][0]); d.setDecMethod(1, cfg[i][1]); d.initCodec(); d.init(48000); d.setDecOrderAllBands(order)
+        for b in range(133):
+            d.setDecOrder(1 + (b + i) % order, b)
+        return d
+    xs = [frames(300 + i, 36, nB * F) for i in range(H)]
+    decs = [mk(saf.AmbiDec, i) for i in range(H)]
+    outs, errs = [None] * H, []
+    start = threading.Barrier(H)
+
+    def work(i):
+        try:
+            start.wait()
+            outs[i] = np.concatenate([decs[i].process(np.ascontiguousarray(xs[i][:, b * F:(b + 1) * F]), 49) for b in range(nB)], 1)
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(H)]
+    for t in ts: t.start()
+    for t in ts: t.join(timeout=300)
+    assert not errs and not any(t.is_alive() for t in ts)
+    for i in range(H):
+        o = mk(orc.AmbiDec, i)
+        yo = np.concatenate([o.process(np.ascontiguousarray(xs[i][:, b * F:(b + 1) * F]), 49) for b in range(nB)], 1)
+        assert relrms(outs[i], yo) < 3e-6, i
+        alone = mk(saf.AmbiDec, i)
+        ya = np.concatenate([alone.process(np.ascontiguousarray(xs[i][:, b * F:(b + 1) * F]), 49) for b in range(nB)], 1)
+        assert np.array_equal(outs[i], ya), i
+
+
 def test_two_threads_create_and_run_operators_concurrently(saf):
     """first use of the library from two threads at once (stream creation and device check are serialised, runtime.cpp)"""
     errs = []

@@ -164,6 +164,42 @@ def test_equaliser_path_batch_split_invariance_and_strides(saf, orc, path):
 
 
 @pytest.mark.parametrize("mode", [1, 2])
+def test_batch_member_reinitialised_mid_stream(saf, orc, path, mode):
+    """One member of a live batch gets another decoder (setDecMethod + initCodec) between two calls: its filterbank restarts from
+    zero like the reference's (ambi_dec_initCodec ends with afSTFT_clearBuffers, ambi_dec.c:218-225), the other instances continue
+    untouched, and the pipeline grows from one dense matrix to two (SAD / SAD -> SAD / EPAD: the equaliser kernel's two-output
+    form, z_1's overlap-add history starting at zero).  Every instance against an oracle handle that gets the same calls."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    path(mode)
+    F, order, nI = 256, 5, 3
+    orders = band_orders(order, 12)
+    x = np.stack([frames(820 + i, 10 * 36, F).reshape(10, 36, F) for i in range(nI)])
+    d_in = torch.from_numpy(x).cuda()
+    st = (10 * 36 * F, 36 * F, F)
+    gs = [make(saf.AmbiDec, F, order, 28, 1, 1, 1, 1, orders) for _ in range(nI)]
+    os_ = [make(orc.AmbiDec, F, order, 28, 1, 1, 1, 1, orders) for _ in range(nI)]
+    bt = saf.AmbiDecBatch(gs, 6)
+    d_out = torch.zeros(nI, 10, 49, F, device="cuda")
+    so = (10 * 49 * F, 49 * F, F)
+    bt.process_ptr(d_in.data_ptr(), st, d_out.data_ptr(), so, 4)
+    torch.cuda.synchronize()
+    yo = [[os_[i].process(x[i, f], 49) for f in range(4)] for i in range(nI)]
+    for d in (gs[1], os_[1]):
+        d.setDecMethod(1, 3); d.initCodec(); d.setDecOrderAllBands(order)
+        for b, o in enumerate(orders):
+            d.setDecOrder(int(o), b)
+    bt.process_ptr(d_in[:, 4:].data_ptr(), st, d_out[:, 4:].data_ptr(), so, 6)
+    torch.cuda.synchronize()
+    assert bt.lastPath() == 1
+    yg = d_out.cpu().numpy()
+    for i in range(nI):
+        y = np.stack(yo[i] + [os_[i].process(x[i, f], 49) for f in range(4, 10)])
+        assert relrms(yg[i], y) < 3e-6 and relrms(yg[i, 4:], y[4:]) < 3e-6, i
+    saf.set_stream(None)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
 def test_equaliser_path_time_chunks_bit_identical(saf, orc, path, mode):
     """one handle rendering many blocks per call: the launch is cut into time chunks (few (channel, instance) workgroups);
     a chunk rebuilds its overlap-add history from the 16 hops before it.  Bit-identical to the same stream in short calls
