@@ -429,7 +429,7 @@ def run_rank(args):
         i = np.arange(64) + 0.5
         fib = np.stack([np.mod(np.degrees(np.pi * (1.0 + 5.0 ** 0.5) * i), 360.0) - 180.0, np.degrees(np.arcsin(1.0 - 2.0 * i / 64))], 1)
         other = []
-        for fn in (lambda: W.binauraliser_batch(L, torch, api), lambda: W.matrixconv(L, torch, api), lambda: W.powermap(L, torch, api),
+        for fn in (lambda: W.binauraliser_batch(L, torch, api), lambda: W.matrixconv(L, torch, api), lambda: W.powermap(L, torch, api), lambda: W.powermap_batch(L, torch, api),
                    lambda: W.enc_dec_chain(L, torch, api, fib)):
             other.append(fn())
 

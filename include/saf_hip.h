@@ -544,6 +544,15 @@ SAF_API int  powermap_getProcessingDelay(void);                                 
 SAF_API void saf_hip_powermap_analysis_dev(void* const hPm, const float* d_in, long long in_frame_stride, long long in_ch_stride, int nInputs, int nFrames);
 /** Read-back for parity checks: Cx as [133][nSH][nSH]; the smoothed map on the 812-point scanning grid (returns its length). */
 SAF_API void saf_hip_powermap_getCx(void* const hPm, float_complex* Cx);
+/* ---- batched, device-resident entry point (PWD mode): nInst initialised handles with the same frame size and master order.  One
+ * call advances every instance by nFrames frames of device-resident samples x[inst*inst_stride + frame*frame_stride + ch*ch_stride + n]
+ * (covariances and filterbank state are the batch's own, zero at creation).  The member handles keep their parameters and receive
+ * the maps they asked for with powermap_requestPmapUpdate: powermap_getPmap / saf_hip_powermap_getRawPmap on a member return the
+ * batch's result.  The call synchronises only when a map was asked for. */
+SAF_API void* saf_hip_powermap_batch_create(void* const* hPms, int nInst, int maxFramesPerCall);
+SAF_API void  saf_hip_powermap_batch_destroy(void** const phBatch);
+SAF_API void  saf_hip_powermap_batch_analysis(void* const hBatch, const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride, int nInputs, int nFrames);
+SAF_API void  saf_hip_powermap_batch_getCx(void* const hBatch, int instIdx, float_complex* Cx);
 SAF_API int  saf_hip_powermap_getRawPmap(void* const hPm, float* pmap);
 /* Activity-map generators on one nSH x nSH covariance matrix (saf_sh.h / saf_sh.c:1544-1858); host pointers.
  * Y_grid: nSH x nGrid_dirs, passed as complex like in the reference but real-valued (it is built from real SH). */

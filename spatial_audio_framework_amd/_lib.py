@@ -404,6 +404,10 @@ def load():
     sig("powermap_getPmap", ci, vp, C.POINTER(fp), C.POINTER(fp), ip, ip, ip, ip)
     sig("saf_hip_powermap_analysis_dev", None, vp, vp, cll, cll, ci, ci)
     sig("saf_hip_powermap_getCx", None, vp, vp)
+    sig("saf_hip_powermap_batch_create", vp, C.POINTER(vp), ci, ci)
+    sig("saf_hip_powermap_batch_destroy", None, C.POINTER(vp))
+    sig("saf_hip_powermap_batch_analysis", None, vp, vp, cll, cll, cll, ci, ci)
+    sig("saf_hip_powermap_batch_getCx", None, vp, ci, vp)
     sig("saf_hip_powermap_getRawPmap", ci, vp, fp)
     _lib = L
     return L

@@ -1075,3 +1075,26 @@ class Powermap:
     def __del__(self):
         if getattr(self, "h", None) and C is not None:
             self.L.powermap_destroy(C.byref(self.h))
+
+
+class PowermapBatch:
+    """saf_hip_powermap_batch_*: nInst initialised handles (PWD mode), device-resident frames."""
+
+    def __init__(self, pms, maxFramesPerCall):
+        self.L = load()
+        self.pms = list(pms)
+        arr = (vp * len(self.pms))(*[p.h for p in self.pms])
+        self.nInst = len(self.pms)
+        self.hb = vp(self.L.saf_hip_powermap_batch_create(arr, self.nInst, maxFramesPerCall))
+
+    def analysis_ptr(self, d_in, strides, nIn, nFrames):
+        """strides = (inst, frame, ch) in floats."""
+        self.L.saf_hip_powermap_batch_analysis(self.hb, vp(d_in), *strides, nIn, nFrames)
+
+    def Cx(self, i, nSH):
+        out = np.zeros((133, nSH, nSH), np.complex64)
+        self.L.saf_hip_powermap_batch_getCx(self.hb, i, out.ctypes.data_as(vp)); return out
+
+    def __del__(self):
+        if getattr(self, "hb", None) and C is not None:
+            self.L.saf_hip_powermap_batch_destroy(C.byref(self.hb))

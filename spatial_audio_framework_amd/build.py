@@ -24,7 +24,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
             "-Wno-unused-result"]
 NO_SLP = ["-fno-slp-vectorize"]
-KEEP_SLP = {"powermap_kernels.hip"}        # its covariance update is 20 % faster with the packed complex MACs (31 vs 39 us)
+KEEP_SLP = set()                           # (round 2 kept it for the vector covariance update of powermap; that kernel is an MFMA kernel now)
 
 
 # per-file additions (experiments: SAF_HIP_FLAGS_<file stem>="-flag1 -flag2")

@@ -55,6 +55,8 @@ struct Powermap {
     int shadowNorm = -1, shadowChOrd = -1, shadowOrder = -1;
 };
 
+static void finish_map_on_host(Powermap* p, const float* pmapDev);
+
 static void set_codec_status(Powermap* p, CODEC_STATUS s)      /* powermap_internal.c:32-44 */
 {
     if (s == CODEC_STATUS_NOT_INITIALISED) while (p->codecStatus == CODEC_STATUS_INITIALISING) psleep_ms(10);
@@ -135,29 +137,192 @@ static void analyse_frames_dev(Powermap* p, const float* d_in, long long in_fram
         const int G = p->grid_nDirs;
         HIP_CHECK(hipMemcpyAsync(p->h_pmap.p, p->d_pmap.p, sizeof(float) * G, hipMemcpyDeviceToHost, stream()));
         HIP_CHECK(hipStreamSynchronize(stream()));
-        memcpy(p->pmap.data(), p->h_pmap.p, sizeof(float) * G);
         /* interpolate to the display grid (powermap.c:350-353: sgemm with the VBAP table, at most three non-zeros per row,
          * added in ascending column order like the dense product) and normalise to 0..1 (:356-364) */
-        std::vector<float>& out = p->pmap_grid[p->dispSlotIdx];
-        for (int i = 0; i < p->interp_nDirs; i++) {
-            float s = 0.0f;
-            for (int q = 0; q < 3; q++) s += p->interpComp[(size_t)i * 3 + q] * p->pmap[p->interpIdx[(size_t)i * 3 + q]];
-            out[i] = s;
-        }
-        float mn = out[0], mx = out[0];
-        for (int i = 1; i < p->interp_nDirs; i++) { if (out[i] < mn) mn = out[i]; if (out[i] > mx) mx = out[i]; }
-        p->pmap_grid_minVal = mn; p->pmap_grid_maxVal = mx;
-        for (int i = 0; i < p->interp_nDirs; i++) out[i] = (out[i] - mn) / (mx - mn + 1e-11f);
-        p->dispSlotIdx++; if (p->dispSlotIdx >= PM_NUM_DISP_SLOTS) p->dispSlotIdx = 0;
-        p->pmapReady = 1;
+        finish_map_on_host(p, p->h_pmap.p);
     }
 }
+
+/* host part of a map update (powermap.c:350-364): interpolation to the display grid, 0..1 normalisation, display slot */
+static void finish_map_on_host(Powermap* p, const float* pmapDev)
+{
+    const int G = p->grid_nDirs;
+    memcpy(p->pmap.data(), pmapDev, sizeof(float) * G);
+    std::vector<float>& out = p->pmap_grid[p->dispSlotIdx];
+    for (int i = 0; i < p->interp_nDirs; i++) {
+        float s = 0.0f;
+        for (int q = 0; q < 3; q++) s += p->interpComp[(size_t)i * 3 + q] * p->pmap[p->interpIdx[(size_t)i * 3 + q]];
+        out[i] = s;
+    }
+    float mn = out[0], mx = out[0];
+    for (int i = 1; i < p->interp_nDirs; i++) { if (out[i] < mn) mn = out[i]; if (out[i] > mx) mx = out[i]; }
+    p->pmap_grid_minVal = mn; p->pmap_grid_maxVal = mx;
+    for (int i = 0; i < p->interp_nDirs; i++) out[i] = (out[i] - mn) / (mx - mn + 1e-11f);
+    p->dispSlotIdx++; if (p->dispSlotIdx >= PM_NUM_DISP_SLOTS) p->dispSlotIdx = 0;
+    p->pmapReady = 1;
+}
+
+/* ---- batch of powermaps (PWD mode): nInst initialised handles with the same frame size and master order; every call advances all
+ *      of them by nFrames frames (own filterbank state and covariances, like the other batches).  The handles keep their parameters
+ *      (per-band orders, EQ, averaging coefficients, conventions) and receive the maps they asked for (powermap_requestPmapUpdate):
+ *      powermap_getPmap / saf_hip_powermap_getRawPmap on a member handle return the batch's result. ---- */
+struct PmBatch {
+    std::vector<Powermap*> inst;
+    int nInst = 0, F = 0, T = 0, order = 0, nSH = 0, maxFrames = 0, Hmax = 0, G = 0;
+    AfState st;
+    DevBuf<float2> X, Cx;
+    DevBuf<float> Cg, pmap, prev, bandScale, chScale, alpha, avg;
+    DevBuf<int> bandNSH, chMap, mapOrder;
+    PinBuf<float> stF, hPmap; PinBuf<int> stI;
+    std::vector<int> shNorm, shChOrd;
+    std::vector<float> shAlpha;
+    bool stagePending = false;
+
+    void create(Powermap* const* h, int n, int maxFrames_)
+    {
+        nInst = n; inst.assign(h, h + n); maxFrames = maxFrames_;
+        Powermap* p0 = inst[0];
+        F = p0->F; T = p0->T; order = p0->masterOrder; nSH = ORDER2NSH(order); G = p0->grid_nDirs;
+        for (int i = 0; i < n; i++) {
+            Powermap* p = inst[i];
+            if (p->codecStatus != CODEC_STATUS_INITIALISED) SAF_FATAL("powermap batch: instance %d is not initialised (call powermap_initCodec)", i);
+            if (p->F != F || p->masterOrder != order) SAF_FATAL("powermap batch: all instances must share frame size and master order");
+            if (p->FIFO_idx != 0) SAF_FATAL("powermap batch: instance %d has a partly filled input FIFO", i);
+        }
+        Hmax = (T * maxFrames + 15) & ~15;
+        st.create(nInst, nSH, 0);
+        X.alloc((size_t)nInst * SAF_NBANDS * SAF_MAXCH * Hmax, true);
+        Cx.alloc((size_t)nInst * SAF_NBANDS * 64 * 64);
+        Cg.alloc((size_t)nInst * 64 * 64); pmap.alloc((size_t)nInst * G); prev.alloc((size_t)nInst * G);
+        bandScale.alloc((size_t)nInst * SAF_NBANDS); bandNSH.alloc((size_t)nInst * SAF_NBANDS);
+        chScale.alloc((size_t)nInst * SAF_MAXCH); chMap.alloc((size_t)nInst * SAF_MAXCH); alpha.alloc(nInst); avg.alloc(nInst); mapOrder.alloc(nInst);
+        stF.ensure((size_t)nInst * (SAF_NBANDS + SAF_MAXCH + 2)); stI.ensure((size_t)nInst * (SAF_NBANDS + SAF_MAXCH + 1)); hPmap.ensure((size_t)nInst * G);
+        shNorm.assign(nInst, -1); shChOrd.assign(nInst, -1); shAlpha.assign(nInst, -1.0f);
+    }
+
+    void analysis(const float* d_in, long long in_inst, long long in_frame, long long in_ch, int nIn, int nFrames)
+    {
+        if (nFrames <= 0) return;
+        if (nFrames > maxFrames) SAF_FATAL("powermap batch: nFrames %d exceeds the maxFramesPerCall %d given at creation", nFrames, maxFrames);
+        const int H = nFrames * T;
+        /* per-instance tables whose inputs changed (conventions, covariance averaging), staged per instance: no sync between instances */
+        bool began = false;
+        auto stage = [&]() { if (!began) { if (stagePending) { HIP_CHECK(hipStreamSynchronize(stream())); stagePending = false; } began = true; } };
+        float* fS = stF.p; int* iS = stI.p;
+        const size_t fPer = SAF_NBANDS + SAF_MAXCH + 2, iPer = SAF_NBANDS + SAF_MAXCH + 1;
+        for (int i = 0; i < nInst; i++) {
+            Powermap* p = inst[i];
+            if (p->pmap_mode != 1 && p->recalcPmap == 1) SAF_FATAL("powermap batch: only the PWD map is batched (instance %d asks for mode %d)", i, p->pmap_mode);
+            if (shNorm[i] != (int)p->norm || shChOrd[i] != (int)p->chOrdering) {
+                stage();
+                int* map = iS + i * iPer + SAF_NBANDS; float* sc = fS + i * fPer + SAF_NBANDS;
+                for (int ch = 0; ch < SAF_MAXCH; ch++) { map[ch] = ch; sc[ch] = 1.0f; }
+                if (p->chOrdering == CH_FUMA) { map[1] = 2; map[2] = 3; map[3] = 1; for (int ch = 4; ch < SAF_MAXCH; ch++) map[ch] = -1; }
+                if (p->norm == NORM_SN3D) { for (int n = 0; n <= order; n++) for (int ch = n * n; ch < ORDER2NSH(n); ch++) sc[ch] = sqrtf(2.0f * (float)n + 1.0f); }
+                else if (p->norm == NORM_FUMA) { sc[0] = sqrtf(2.0f); for (int ch = 1; ch < 4; ch++) sc[ch] = sqrtf(3.0f); }
+                HIP_CHECK(hipMemcpyAsync(chMap.p + (size_t)i * SAF_MAXCH, map, sizeof(int) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
+                HIP_CHECK(hipMemcpyAsync(chScale.p + (size_t)i * SAF_MAXCH, sc, sizeof(float) * SAF_MAXCH, hipMemcpyHostToDevice, stream()));
+                shNorm[i] = (int)p->norm; shChOrd[i] = (int)p->chOrdering;
+            }
+            const float al = p->covAvgCoeff < PM_MAX_COV_AVG_COEFF ? p->covAvgCoeff : PM_MAX_COV_AVG_COEFF;
+            if (shAlpha[i] != al) {
+                stage();
+                float* slot = fS + i * fPer + SAF_NBANDS + SAF_MAXCH;
+                slot[0] = al;
+                HIP_CHECK(hipMemcpyAsync(alpha.p + i, slot, sizeof(float), hipMemcpyHostToDevice, stream()));
+                shAlpha[i] = al;
+            }
+        }
+        AnaLaunch a{};
+        a.in = d_in; a.in_inst = in_inst; a.in_ch = in_ch; a.in_frame = in_frame; a.hopsPerFrame = T; a.nChIn = nIn;
+        a.hist_rd = st.ana[st.anaPar].p; a.hist_wr = st.ana[st.anaPar ^ 1].p;
+        a.out = X.p; a.out_inst = (long long)SAF_NBANDS * SAF_MAXCH * Hmax; a.out_band = (long long)SAF_MAXCH * Hmax; a.out_ch = Hmax;
+        a.ch_scale = chScale.p; a.ch_map = chMap.p; a.tab_stride = SAF_MAXCH;
+        a.nCh = nSH; a.nInst = nInst; a.H = H; a.lowDelay = 0; a.hybrid = 1;
+        launch_analysis(a);
+        st.anaPar ^= 1;
+
+        CovLaunch c{};
+        c.X = X.p; c.x_inst = a.out_inst; c.x_band = a.out_band; c.x_ch = a.out_ch; c.Cx = Cx.p; c.cx_inst = (long long)SAF_NBANDS * 64 * 64;
+        c.nSH = nSH; c.T = T; c.nFrames = nFrames; c.nInst = nInst; c.alphaInst = alpha.p; c.alpha = 0.0f;
+        launch_cov_update(c);
+
+        /* maps for the instances that asked (powermap.c:270-272): one launch pair over all instances, the others' workgroups leave */
+        std::vector<int> want;
+        for (int i = 0; i < nInst; i++) if (inst[i]->recalcPmap == 1) want.push_back(i);
+        if (!want.empty()) {
+            stage();
+            for (int i = 0; i < nInst; i++) {
+                Powermap* p = inst[i];
+                int* io = iS + i * iPer; float* fo = fS + i * fPer;
+                int maxOrder = 1;
+                for (int band = 0; band < SAF_NBANDS; band++) {
+                    int ob = p->analysisOrderPerBand[band] < order ? p->analysisOrderPerBand[band] : order; if (ob < 1) ob = 1;
+                    if (ob > maxOrder) maxOrder = ob;
+                    float eq = p->pmapEQ[band]; eq = eq < 0.0f ? 0.0f : (eq > 2.0f ? 2.0f : eq);
+                    io[band] = ORDER2NSH(ob); fo[band] = 1e3f * eq;
+                }
+                io[SAF_NBANDS + SAF_MAXCH] = p->recalcPmap == 1 ? maxOrder : 0;
+                fo[SAF_NBANDS + SAF_MAXCH + 1] = p->pmapAvgCoeff;
+                if (p->recalcPmap != 1) continue;
+                HIP_CHECK(hipMemcpyAsync(bandNSH.p + (size_t)i * SAF_NBANDS, io, sizeof(int) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
+                HIP_CHECK(hipMemcpyAsync(bandScale.p + (size_t)i * SAF_NBANDS, fo, sizeof(float) * SAF_NBANDS, hipMemcpyHostToDevice, stream()));
+                HIP_CHECK(hipMemcpyAsync(avg.p + i, fo + SAF_NBANDS + SAF_MAXCH + 1, sizeof(float), hipMemcpyHostToDevice, stream()));
+            }
+            for (int i = 0; i < nInst; i++)
+                HIP_CHECK(hipMemcpyAsync(mapOrder.p + i, iS + i * iPer + SAF_NBANDS + SAF_MAXCH, sizeof(int), hipMemcpyHostToDevice, stream()));
+            PwdLaunch w{};
+            w.Cx = Cx.p; w.cx_inst = c.cx_inst; w.bandScale = bandScale.p; w.bandNSH = bandNSH.p; w.Cg = Cg.p;
+            w.pmap = pmap.p; w.prev_pmap = prev.p; w.G = G; w.nInst = nInst; w.mapOrder = mapOrder.p; w.avgInst = avg.p;
+            for (int n = 0; n < order; n++) w.YgridByOrder[n] = inst[0]->Ygrid[n].p;
+            w.Ygrid = inst[0]->Ygrid[order - 1].p; w.nM = nSH; w.avg = 0.0f;
+            launch_pwd_map(w);
+            HIP_CHECK(hipMemcpyAsync(hPmap.p, pmap.p, sizeof(float) * (size_t)nInst * G, hipMemcpyDeviceToHost, stream()));
+            HIP_CHECK(hipStreamSynchronize(stream()));
+            stagePending = false; began = false;
+            for (int i : want) { inst[i]->recalcPmap = 0; inst[i]->pmapReady = 0; finish_map_on_host(inst[i], hPmap.p + (size_t)i * G); }
+        }
+        if (began) stagePending = true;
+    }
+};
 
 }  // namespace saf
 
 using namespace saf;
 
 extern "C" {
+
+void* saf_hip_powermap_batch_create(void* const* hPms, int nInst, int maxFramesPerCall)
+{
+    if (nInst <= 0 || maxFramesPerCall <= 0) SAF_FATAL("powermap batch: nInst and maxFramesPerCall must be positive");
+    ensure_device();
+    PmBatch* b = new PmBatch();
+    b->create((Powermap* const*)hPms, nInst, maxFramesPerCall);
+    return b;
+}
+void saf_hip_powermap_batch_destroy(void** const phBatch)
+{
+    if (!phBatch || !*phBatch) return;
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    delete (PmBatch*)*phBatch;
+    *phBatch = nullptr;
+}
+void saf_hip_powermap_batch_analysis(void* const hBatch, const float* d_in, long long in_inst_stride, long long in_frame_stride, long long in_ch_stride, int nInputs, int nFrames)
+{
+    PmBatch* b = (PmBatch*)hBatch;
+    b->analysis(d_in, in_inst_stride, in_frame_stride, in_ch_stride, nInputs, nFrames);
+}
+void saf_hip_powermap_batch_getCx(void* const hBatch, int instIdx, float_complex* Cx)
+{
+    PmBatch* b = (PmBatch*)hBatch;
+    if (instIdx < 0 || instIdx >= b->nInst) SAF_FATAL("powermap batch: instance index out of range");
+    const int nSH = b->nSH;
+    std::vector<float2> h((size_t)SAF_NBANDS * 64 * 64);
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    HIP_CHECK(hipMemcpy(h.data(), b->Cx.p + (size_t)instIdx * SAF_NBANDS * 64 * 64, sizeof(float2) * h.size(), hipMemcpyDeviceToHost));
+    float2* o = reinterpret_cast<float2*>(Cx);
+    for (int bd = 0; bd < SAF_NBANDS; bd++) for (int i = 0; i < nSH; i++) for (int j = 0; j < nSH; j++) o[((size_t)bd * nSH + i) * nSH + j] = h[(size_t)bd * 4096 + i * 64 + j];
+}
 
 void saf_hip_powermap_setFrameSize(int frameSize)
 {

@@ -3,8 +3,8 @@
  *
  *   cov_update_kernel  per band  Cx <- a*Cx + (1-a) * X X^H  over the T time slots of a frame (powermap.c:258-267:
  *                      cblas_cgemm NoTrans/ConjTrans + sscal + saxpy), frame after frame inside one launch so the
- *                      4.4 MB of covariance matrices cross HBM once per call.  One workgroup per band and 32 x 32 quadrant, a
- *                      16 x 16 thread grid of 2 x 2 register blocks; up to 128 time slots of spectra staged in LDS per round.
+ *                      4.4 MB of covariance matrices cross HBM once per call.  fp32 MFMA: one workgroup per (band, instance),
+ *                      four waves = the four 32 x 32 quadrants, 64 time slots of spectra staged in LDS per round.
  *   cgrp_kernel        C_grp = sum_band 1e3*EQ_b * Cx_b (top-left block of the band's order), bands in ascending order
  *                      (powermap.c:281-289).  Only Re(C_grp) is kept: the PWD map is y^T C y with a REAL steering
  *                      vector, so Im(C) cannot reach the real part.
@@ -17,36 +17,43 @@ namespace saf {
 
 struct CovArgs { CovLaunch l; };
 
-/* grid (band, quadrant): a workgroup owns one 32 x 32 quadrant of the band's covariance matrix, a 16 x 16 thread grid of
- * 2 x 2 register blocks (rows i, i + 16 / columns j, j + 16 of the quadrant: consecutive lanes read consecutive LDS rows whose
- * stride is odd in 8-byte words, conflict-free).  Rounds of up to COV_SLOTS time slots: the rows of the quadrant's two channel
- * groups are staged in LDS by ONE wave of loads, then the frames are multiplied out of LDS one after the other with the
- * reference's update per frame (same arithmetic per matrix element as one workgroup per band: 4 x the workgroups, a quarter of
- * the arithmetic each; one workgroup per band with one frame per round was 32 us, latency- and issue-bound on half the chip). */
-#define COV_SLOTS 128
+/* The covariance update on the fp32 matrix cores.  X X^H of a frame (64 channels x T time slots, complex) as two REAL products over
+ * K = 2 T: with P[i][2t] = Re x_i[t], P[i][2t+1] = Im x_i[t] and Q[i][2t] = Im x_i[t], Q[i][2t+1] = -Re x_i[t]
+ *     Re (X X^H) = P P^T,      Im (X X^H) = Q P^T
+ * so one time slot is ONE k-pair step of v_mfma_f32_32x32x2_f32 for each of the two: the A operand of lane l is component
+ * (l >> 5) of x_row(l & 31)[t] (for Q: the other component, sign flipped for Re), the B operand component (l >> 5) of
+ * x_col(l & 31)[t].  grid (band, instance), 4 waves = the four 32 x 32 quadrants of the 64 x 64 matrix, their running
+ * covariance in 2 x 16 accumulator registers per lane for the whole launch; the frames of a call are multiplied out of LDS one
+ * after the other with the reference's update per frame (cblas_sscal by alpha, cblas_saxpy of (1 - alpha) X X^H: powermap.c:262-266),
+ * so the 4.4 MB of covariances of an instance cross HBM once per call.  Rounds of COV_SLOTS time slots are staged in LDS by one
+ * wave of coalesced loads (row stride odd in 8-byte words: the operand reads of a step are conflict-free).
+ * Against round 2's vector kernel (16 x 16 threads x 2 x 2 register blocks): 558 MFLOP per 16 frames in 26 us = 21 TFLOP/s. */
+#define COV_SLOTS 64
+typedef float cov_f16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
 {
-    extern __shared__ float2 s_x[];                          /* [64][ld]: rows 0..31 = the quadrant's i channels, 32..63 = its j channels */
+    __shared__ float2 s_x[64 * (COV_SLOTS + 1)];             /* [channel][slot], 33 KB */
     const CovLaunch& l = a.l;
-    const int band = blockIdx.x;
-    const int qi = (blockIdx.y >> 1) * 32, qj = (blockIdx.y & 1) * 32;
-    const int tid = threadIdx.x;
-    const int ti = tid >> 4, tj = tid & 15;                  /* rows ti, ti + 16 and columns tj, tj + 16 of the quadrant */
+    const int band = blockIdx.x, inst = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int qi = (wv >> 1) * 32, qj = (wv & 1) * 32;      /* this wave's quadrant */
+    const int kh = lane >> 5, lr = lane & 31;
     const int nSH = l.nSH, T = l.T;
-    if (qi >= nSH || qj >= nSH) return;                      /* (uniform) nothing of this quadrant exists */
+    const bool quadOn = qi < nSH && qj < nSH;                /* (uniform per wave) */
     const int fpr = COV_SLOTS / T;                            /* frames per round */
-    const int ld = fpr * T + 1;
-    float2* C = l.Cx + (long long)band * 64 * 64;
-    float2 c[2][2];
+    const int ld = COV_SLOTS + 1;
+    float2* C = l.Cx + (long long)inst * l.cx_inst + (long long)band * 64 * 64;
+    cov_f16 cr, ci;
 #pragma unroll
-    for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int v = 0; v < 2; v++) {
-            const int i = qi + ti + 16 * u, j = qj + tj + 16 * v;
-            c[u][v] = (i < nSH && j < nSH) ? C[i * 64 + j] : make_float2(0.f, 0.f);
-        }
-    const float2* X = l.X + (long long)band * l.x_band;
-    const float al = l.alpha, be = 1.0f - l.alpha;
+    for (int r = 0; r < 16; r++) {                            /* register r of this lane: row (r & 3) + 8 (r >> 2) + 4 kh, column lr */
+        const int i = qi + (r & 3) + 8 * (r >> 2) + 4 * kh, j = qj + lr;
+        const float2 v = (quadOn && i < nSH && j < nSH) ? C[i * 64 + j] : make_float2(0.f, 0.f);
+        cr[r] = v.x; ci[r] = v.y;
+    }
+    const float2* X = l.X + (long long)inst * l.x_inst + (long long)band * l.x_band;
+    const float al = l.alphaInst ? l.alphaInst[inst] : l.alpha, be = 1.0f - al;
+    const float2* xi = s_x + (qi + lr) * ld;
+    const float2* xj = s_x + (qj + lr) * ld;
     for (int f0 = 0; f0 < l.nFrames; f0 += fpr) {
         const int nf = min(fpr, l.nFrames - f0), K = nf * T;  /* slots of this round */
         __syncthreads();
@@ -56,64 +63,48 @@ __global__ __launch_bounds__(256) void cov_update_kernel(CovArgs a)
 #pragma unroll
         for (int q = 0; q < COV_SLOTS * 64 / 256; q++) {
             const int idx = tid + 256 * q, r = idx / COV_SLOTS, t = idx - r * COV_SLOTS;
-            const int ch = r < 32 ? qi + r : qj + r - 32;
-            pre[q] = X[(long long)(ch < nSH ? ch : nSH - 1) * l.x_ch + f0 * T + (t < K ? t : K - 1)];
+            pre[q] = X[(long long)(r < nSH ? r : nSH - 1) * l.x_ch + f0 * T + (t < K ? t : K - 1)];
         }
 #pragma unroll
         for (int q = 0; q < COV_SLOTS * 64 / 256; q++) {
             const int idx = tid + 256 * q, r = idx / COV_SLOTS, t = idx - r * COV_SLOTS;
-            const int ch = r < 32 ? qi + r : qj + r - 32;
-            if (t < K) s_x[r * ld + t] = ch < nSH ? pre[q] : make_float2(0.f, 0.f);
+            s_x[r * ld + t] = r < nSH ? pre[q] : make_float2(0.f, 0.f);
         }
         __syncthreads();
-        for (int f = 0; f < nf; f++) {
-            float2 n[2][2];
+        if (quadOn)
+            for (int f = 0; f < nf; f++) {
+                cov_f16 nr, ni;
 #pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int v = 0; v < 2; v++) n[u][v] = make_float2(0.f, 0.f);
+                for (int r = 0; r < 16; r++) { nr[r] = 0.0f; ni[r] = 0.0f; }
 #pragma unroll 8
-            for (int t = f * T; t < f * T + T; t++) {
-                float2 xi[2], xj[2];
-#pragma unroll
-                for (int u = 0; u < 2; u++) { xi[u] = s_x[(ti + 16 * u) * ld + t]; xj[u] = s_x[(32 + tj + 16 * u) * ld + t]; }
-#pragma unroll
-                for (int u = 0; u < 2; u++)
-#pragma unroll
-                    for (int v = 0; v < 2; v++) {        /* x_i * conj(x_j) */
-                        n[u][v].x = fmaf(xi[u].x, xj[v].x, n[u][v].x); n[u][v].x = fmaf(xi[u].y, xj[v].y, n[u][v].x);
-                        n[u][v].y = fmaf(xi[u].y, xj[v].x, n[u][v].y); n[u][v].y = fmaf(-xi[u].x, xj[v].y, n[u][v].y);
-                    }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-#pragma unroll
-                for (int v = 0; v < 2; v++) {
-                    c[u][v].x = c[u][v].x * al; c[u][v].y = c[u][v].y * al;                     /* cblas_sscal */
-                    c[u][v].x = fmaf(be, n[u][v].x, c[u][v].x); c[u][v].y = fmaf(be, n[u][v].y, c[u][v].y);   /* cblas_saxpy */
+                for (int t = f * T; t < f * T + T; t++) {
+                    const float2 vi = xi[t], vj = xj[t];
+                    const float b = kh ? vj.y : vj.x;
+                    nr = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? vi.y : vi.x, b, nr, 0, 0, 0);
+                    ni = __builtin_amdgcn_mfma_f32_32x32x2f32(kh ? -vi.x : vi.y, b, ni, 0, 0, 0);
                 }
-        }
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    cr[r] = cr[r] * al; ci[r] = ci[r] * al;                                   /* cblas_sscal */
+                    cr[r] = fmaf(be, nr[r], cr[r]); ci[r] = fmaf(be, ni[r], ci[r]);          /* cblas_saxpy */
+                }
+            }
     }
+    if (!quadOn) return;
 #pragma unroll
-    for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int v = 0; v < 2; v++) {
-            const int i = qi + ti + 16 * u, j = qj + tj + 16 * v;
-            if (i < nSH && j < nSH) C[i * 64 + j] = c[u][v];
-        }
+    for (int r = 0; r < 16; r++) {
+        const int i = qi + (r & 3) + 8 * (r >> 2) + 4 * kh, j = qj + lr;
+        if (i < nSH && j < nSH) C[i * 64 + j] = make_float2(cr[r], ci[r]);
+    }
 }
 
 void launch_cov_update(const CovLaunch& l)
 {
-    if (l.nFrames <= 0) return;
-    if (l.T > 16) SAF_FATAL("powermap: more than 16 time slots per frame are not supported (frame size <= 2048)");
+    if (l.nFrames <= 0 || l.nInst <= 0) return;
+    if (l.T > 16 || COV_SLOTS % l.T != 0) SAF_FATAL("powermap: the time slots per frame must divide 64 (frame sizes 128 ... 2048 in powers of two)");
     CovArgs a; a.l = l;
-    const size_t lds = sizeof(float2) * 64 * ((size_t)(COV_SLOTS / l.T) * l.T + 1);
-    /* 66 KB of dynamic LDS: above the 64 KB a kernel gets without asking (set once; thread-safe static initialisation) */
-    static const int attr_set = []() { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(cov_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (COV_SLOTS + 1) * (int)sizeof(float2))); return 1; }();
-    (void)attr_set;
     KernelTimer kt("cov_update");
-    hipLaunchKernelGGL(cov_update_kernel, dim3(SAF_NBANDS, 4), dim3(256), lds, stream(), a);
+    hipLaunchKernelGGL(cov_update_kernel, dim3(SAF_NBANDS, l.nInst), dim3(256), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -126,20 +117,24 @@ __global__ __launch_bounds__(256) void cgrp_kernel(PwdArgs a)
 {
     __shared__ float s_p[4][64];
     const PwdLaunch& l = a.l;
+    const int inst = blockIdx.y;
+    if (l.mapOrder && l.mapOrder[inst] == 0) return;          /* (uniform) no map asked for this instance */
     const int i = blockIdx.x, j = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int per = (l.nBands + 3) / 4;
     const int b0 = g * per, b1 = b0 + per < l.nBands ? b0 + per : l.nBands;
     float acc = 0.0f;
-    const float2* Ce = l.Cx + i * 64 + j;
+    const float2* Ce = l.Cx + (long long)inst * l.cx_inst + i * 64 + j;
+    const int* bandNSH = l.bandNSH + (l.nInst > 1 ? inst * l.nBands : 0);
+    const float* bandScale = l.bandScale + (l.nInst > 1 ? inst * l.nBands : 0);
 #pragma unroll 17
     for (int band = b0; band < b1; band++) {
-        const int ns = l.bandNSH[band];
-        const float v = Ce[(long long)band * 64 * 64].x * l.bandScale[band];      /* crmulf then ccaddf (powermap.c:288) */
+        const int ns = bandNSH[band];
+        const float v = Ce[(long long)band * 64 * 64].x * bandScale[band];      /* crmulf then ccaddf (powermap.c:288) */
         acc += (i < ns && j < ns) ? v : 0.0f;
     }
     s_p[g][j] = acc;
     __syncthreads();
-    if (g == 0) l.Cg[i * 64 + j] = ((s_p[0][j] + s_p[1][j]) + s_p[2][j]) + s_p[3][j];
+    if (g == 0) l.Cg[(long long)inst * 64 * 64 + i * 64 + j] = ((s_p[0][j] + s_p[1][j]) + s_p[2][j]) + s_p[3][j];
 }
 
 /* 256 threads = 64 directions x 4 row groups: thread (d, g) forms sum_{i in 16 g .. 16 g + 15} y_i (C y)_i; the four
@@ -149,16 +144,21 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwdArgs a)
     __shared__ float s_C[64 * 64];
     __shared__ float s_part[4][64];
     const PwdLaunch& l = a.l;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) s_C[e] = l.Cg[e];
+    const int inst = blockIdx.y;
+    const int mo = l.mapOrder ? l.mapOrder[inst] : -1;
+    if (mo == 0) return;                                   /* (uniform) no map asked for this instance */
+    const int nM = mo > 0 ? (mo + 1) * (mo + 1) : l.nM;
+    const float* Ygrid = mo > 0 ? l.YgridByOrder[mo - 1] : l.Ygrid;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) s_C[e] = l.Cg[(long long)inst * 64 * 64 + e];
     const int dl = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int d = blockIdx.x * 64 + dl;
     const int dc = d < l.G ? d : l.G - 1;
     float y[64];
 #pragma unroll
-    for (int i = 0; i < 64; i++) { const float v = l.Ygrid[(long long)(i < l.nM ? i : 0) * l.G + dc]; y[i] = i < l.nM ? v : 0.0f; }
+    for (int i = 0; i < 64; i++) { const float v = Ygrid[(long long)(i < nM ? i : 0) * l.G + dc]; y[i] = i < nM ? v : 0.0f; }
     float yrow[16];                                        /* y_i of this thread's rows (y[] is indexed statically only) */
 #pragma unroll
-    for (int ii = 0; ii < 16; ii++) { const int i = g * 16 + ii; const float v = l.Ygrid[(long long)(i < l.nM ? i : 0) * l.G + dc]; yrow[ii] = i < l.nM ? v : 0.0f; }
+    for (int ii = 0; ii < 16; ii++) { const int i = g * 16 + ii; const float v = Ygrid[(long long)(i < nM ? i : 0) * l.G + dc]; yrow[ii] = i < nM ? v : 0.0f; }
     __syncthreads();
     float acc = 0.0f;
 #pragma unroll
@@ -173,17 +173,20 @@ __global__ __launch_bounds__(256) void pwd_kernel(PwdArgs a)
     __syncthreads();
     if (g != 0 || d >= l.G) return;
     const float tot = ((s_part[0][dl] + s_part[1][dl]) + s_part[2][dl]) + s_part[3][dl];
-    const float v = (1.0f - l.avg) * tot + l.avg * l.prev_pmap[d];
-    l.pmap[d] = v;
-    l.prev_pmap[d] = v;
+    const float avg = l.avgInst ? l.avgInst[inst] : l.avg;
+    const long long o = (long long)inst * l.G + d;
+    const float v = (1.0f - avg) * tot + avg * l.prev_pmap[o];
+    l.pmap[o] = v;
+    l.prev_pmap[o] = v;
 }
 
 void launch_pwd_map(const PwdLaunch& l)
 {
     PwdArgs a; a.l = l;
     KernelTimer kt("pwd_map");
-    hipLaunchKernelGGL(cgrp_kernel, dim3(64), dim3(256), 0, stream(), a);
-    hipLaunchKernelGGL(pwd_kernel, dim3((l.G + 63) / 64), dim3(256), 0, stream(), a);
+    const int nI = l.nInst > 0 ? l.nInst : 1;
+    hipLaunchKernelGGL(cgrp_kernel, dim3(64, nI), dim3(256), 0, stream(), a);
+    hipLaunchKernelGGL(pwd_kernel, dim3((l.G + 63) / 64, nI), dim3(256), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -339,10 +339,12 @@ struct PanGainLaunch {          /* per moved source: table row -> per-band p-nor
 void launch_panner_gains(const PanGainLaunch& l);
 
 /* ---- powermap kernels (powermap_kernels.hip) ---- */
-struct CovLaunch {              /* Cx[b] <- a Cx[b] + (1-a) X_f X_f^H for consecutive frames f (powermap.c:258-267) */
+struct CovLaunch {              /* Cx[b] <- a Cx[b] + (1-a) X_f X_f^H for consecutive frames f (powermap.c:258-267), for nInst instances */
     const float2* X; long long x_band, x_ch;     /* spectra [band][ch][hop] */
     float2* Cx;                 /* [133][64][64] */
     int nSH, T, nFrames; float alpha;
+    int nInst = 1; long long x_inst = 0, cx_inst = 0;      /* batches: per-instance strides in float2 elements */
+    const float* alphaInst = nullptr;                       /* [nInst] per-instance averaging coefficient (else `alpha` for all) */
 };
 void launch_cov_update(const CovLaunch& l);
 struct PwdLaunch {              /* grouped covariance + PWD map + temporal smoothing (powermap.c:276-347, saf_sh.c:1544-1584) */
@@ -352,6 +354,11 @@ struct PwdLaunch {              /* grouped covariance + PWD map + temporal smoot
     float* pmap; float* prev_pmap;
     int nM, G; float avg;
     int nBands = SAF_NBANDS;
+    /* batches: instance i uses Cx + i*cx_inst, bandScale / bandNSH + i*133, Cg + i*4096, pmap / prev_pmap + i*G, and the grid table of
+     * its own order mapOrder[i] (1..7; 0: no map asked for this instance, its workgroups leave); avgInst[i] replaces avg */
+    int nInst = 1; long long cx_inst = 0;
+    const int* mapOrder = nullptr; const float* avgInst = nullptr;
+    const float* YgridByOrder[SAF_MAX_ORDER] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 void launch_pwd_map(const PwdLaunch& l);
 struct AdaptMapLaunch {         /* MVDR / CroPaC-LCMV / MUSIC / MinNorm maps (powermap.c:294-341, saf_sh.c:1586-1858) */

@@ -47,6 +47,55 @@ def test_powermap_cfg4_order7_vs_oracle(saf, orc):
     assert relrms(g.Cx(nSH), o.Cx(nSH)) < TOL
 
 
+def test_powermap_batch_16_handles_order7_vs_oracle(saf, orc):
+    """BASELINE configs[3] as a batch (saf_hip_powermap_batch_*): 16 handles, order 7, F = 1024, their own per-band orders, EQ and
+    averaging coefficients, several frames per call, maps asked by some handles on some calls — covariances (fp32 MFMA update) and
+    PWD maps of every handle against an oracle handle that gets the same frames one by one.  1e-5 relative RMS."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    order, F, nSH, nI = 7, 1024, 64, 16
+    calls = (1, 3, 1, 4)                                # frames per call (a new handle has a map request pending, powermap.c:92: the first call is one frame so that batch and frame-by-frame oracle serve it on the same frame)
+    nF = sum(calls)
+
+    def cfg(pm, i):
+        for b in range(40 + 3 * i, 133):
+            pm.setAnaOrder(1 + (b + i) % 7, b)
+        pm.setPowermapEQ(0.5, 10 + i); pm.setPowermapEQ(0.0, 100)
+        pm.setCovAvgCoeff(0.05 * (i % 8)); pm.setPowermapAvgCoeff(0.1 * (i % 7))
+    gs, os_ = [mk(saf.Powermap, F, order, norm=1 + i % 2) for i in range(nI)], [mk(orc.Powermap, F, order, norm=1 + i % 2) for i in range(nI)]
+    for i in range(nI):
+        cfg(gs[i], i); cfg(os_[i], i)
+    rng = np.random.default_rng(5)
+    xs = []
+    for i in range(nI):
+        dirs = np.stack([rng.uniform(-180, 180, 2), rng.uniform(-60, 60, 2)], 1).astype(np.float32)
+        s = frames(30 + i, 2, nF * F) * np.array([[1.0], [0.6]], np.float32)
+        xs.append((orc.getRSH(order, dirs) @ s + 0.05 * frames(60 + i, nSH, nF * F)).astype(np.float32))
+    x = np.stack(xs)                                    # [inst][ch][time]
+    d_in = torch.from_numpy(x).cuda()
+    bt = saf.PowermapBatch(gs, max(calls))
+    f0 = 0
+    for c, n in enumerate(calls):
+        ask = list(range(nI)) if c == 0 else [i for i in range(nI) if (i + c) % 3 != 1]
+        if c > 0:
+            for i in ask:
+                gs[i].requestPmapUpdate()
+        bt.analysis_ptr(d_in[:, :, f0 * F:].data_ptr(), (nSH * nF * F, F, nF * F), nSH, n)
+        for i in range(nI):
+            for f in range(f0, f0 + n):
+                if c > 0 and i in ask and f == f0 + n - 1:
+                    os_[i].requestPmapUpdate()
+                os_[i].analysis(x[i][:, f * F:(f + 1) * F])
+        for i in ask:
+            assert relrms(gs[i].rawPmap(), os_[i].rawPmap()) < TOL, (c, i)
+            mg, mo = gs[i].getPmap(), os_[i].getPmap()
+            assert maxabs(mg, mo) < 1e-4 and mg.argmax() == mo.argmax()
+        f0 += n
+    for i in range(nI):
+        assert relrms(bt.Cx(i, nSH), os_[i].Cx(nSH)) < TOL, i
+    saf.set_stream(None)
+
+
 def test_powermap_fifo_partial_blocks_and_flags(saf, orc):
     """Sample-wise FIFO (powermap.c:222-230): odd block sizes, isPlaying = 0 drops the frame, first order FuMa input."""
     order, F = 1, 256
