@@ -61,7 +61,9 @@ typedef enum {                      /* afSTFTlib.h:79-83 */
     AFSTFT_TIME_CH_BANDS
 } AFSTFT_FDDATA_FORMAT;
 
-/** afSTFTlib.h:107 / afSTFTlib.c:142.  hopsize 64, 128 or 256 (what the reference accepts in hybrid mode, afSTFTlib.c:158-159).
+/** afSTFTlib.h:107 / afSTFTlib.c:142.  hopsize 64, 128 or 256 — exactly what the reference accepts in hybrid mode
+ *  (afSTFTlib.c:158-159).  LIMITATION: with hybridmode = 0 the reference also takes any other hop that divides 1024 (32, 512,
+ *  1024 ...); this library aborts with a message for those.
  *  128 — the value every operator of the path fixes (ambi_dec_internal.h:68, binauraliser_internal.h:63, powermap_internal.h:67)
  *  — runs the tuned kernels; 64 and 256 run generic, untuned kernels (csrc/afstft_generic.hip) of the same algorithm. */
 SAF_API void afSTFT_create(void** const phSTFT, int nCHin, int nCHout, int hopsize, int lowDelayMode, int hybridmode, AFSTFT_FDDATA_FORMAT format);

@@ -139,9 +139,11 @@ extern "C" {
 void afSTFT_create(void** const phSTFT, int nCHin, int nCHout, int hopsize, int lowDelayMode, int hybridmode, AFSTFT_FDDATA_FORMAT format)
 {
     ensure_device();
-    /* afSTFTlib.c:158-159: 64, 128 or 256 in hybrid mode.  128 runs the tuned kernels, 64 / 256 the generic ones. */
+    /* afSTFTlib.c:158-159 restricts the hop to 64, 128 or 256 in HYBRID mode only; without the hybrid filters the reference takes any
+     * hop that divides 1024.  Here 64 / 128 / 256 exist in both modes (128: the tuned kernels, 64 / 256: the generic ones); the other
+     * non-hybrid hops (32, 512, 1024 ...) are a stated limitation of this library (include/saf_hip.h), not of the reference. */
     if (hopsize != 64 && hopsize != 128 && hopsize != 256)
-        SAF_FATAL("afSTFT_create: hopsize %d is not supported (64, 128 or 256)", hopsize);
+        SAF_FATAL("afSTFT_create: hopsize %d is not supported by libsaf_hip (64, 128 or 256; the reference also accepts other divisors of 1024 when hybridmode = 0)", hopsize);
     AfSTFT* h = new AfSTFT();
     h->hop = hopsize; h->lowDelay = lowDelayMode ? 1 : 0; h->hybrid = hybridmode ? 1 : 0; h->format = format;
     h->nBands = hybridmode ? hopsize + 5 : hopsize + 1;                       /* afSTFTlib.c:165 */

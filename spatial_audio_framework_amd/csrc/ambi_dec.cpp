@@ -441,9 +441,11 @@ struct DecPipeline {
         }
         const int H = nFrames * T;
         const int mode = g_ambi_dec_time_domain;
-        /* the time-domain GEMM writes the caller's block with 16-byte stores */
-        bool eq = !bin && mode != 0 && synDomain != DOM_LS &&
-                  ((out_inst | out_frame | out_ch) & 3) == 0 && (((uintptr_t)d_out) & 15) == 0;
+        /* (an output block at an odd offset stays on this path too: the time-domain GEMM then writes it with 4-byte stores —
+         * a pipeline only leaves the equaliser path for an explicit mode 0, a two-decoder pipeline with such an output, or
+         * binauralised output) */
+        const bool outOdd = ((out_inst | out_frame | out_ch) & 3) != 0 || (((uintptr_t)d_out) & 15) != 0;
+        bool eq = !bin && mode != 0 && synDomain != DOM_LS && !(outOdd && two_dense_matrices());
         if (eq) {
             refresh_eq(mode);
             const long long zCh = (long long)Hmax * SAF_HOP, zInst = (long long)SAF_MAXCH * zCh, zD = (long long)nInst * zInst;

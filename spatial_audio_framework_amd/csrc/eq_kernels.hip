@@ -599,6 +599,9 @@ bool launch_eq_decode(const EqLaunch& e, const EqDecodeTail& d, unsigned* done, 
     /* every workgroup of the launch must be resident at once (6 per compute unit on 256 compute units, with a margin for other
      * streams' launches): a waiting decode workgroup then never keeps a channel workgroup of its launch off the chip */
     if ((long long)e.nInst * (e.nCh + nDec) > 768) return false;
+    /* ... and only for a few blocks per call: the decode tail is built for latency (half a tile's operands in flight), the
+     * stand-alone GEMM for throughput */
+    if (units > 16) return false;
     const long long chSpan = (long long)(e.nChIn > 0 ? e.nChIn : 1) * e.in_ch;
     const long long hopSpan = (long long)((e.H + e.hopsPerFrame - 1) / e.hopsPerFrame) * e.in_frame + (long long)e.hopsPerFrame * SAF_HOP;
     if (e.in_ch < 0 || e.in_frame < 0 || e.H >= (1 << 22) || (chSpan + hopSpan) * 4 >= (1ll << 32))

@@ -20,6 +20,10 @@
 #include "saf_hip_common.h"
 #include "mfma_tile.h"
 #include "afstft_device.h"
+#include <algorithm>
+#include <climits>
+#include <mutex>
+#include <utility>
 
 namespace saf {
 
@@ -27,7 +31,7 @@ namespace saf {
 /*                               band GEMM                                    */
 /* ========================================================================== */
 
-struct GemmArgs { BandGemmLaunch g; int unitsPerInst, nColTiles, G; };
+struct GemmArgs { BandGemmLaunch g; int unitsPerInst, nColTiles, G; int scalarStores; };      /* scalarStores: Y is not 16-byte aligned / strided: four 4-byte stores per lane */
 
 /* Workgroup = 2 waves = the two 32-row halves of 64 x 128 output tiles.  A workgroup owns G consecutive
  * (band, column tile) units of one instance and software-pipelines them: while the matrix cores work on one half
@@ -106,7 +110,10 @@ __global__ __launch_bounds__(128, 1) void band_gemm_kernel(GemmArgs a)
                 const float4 v = make_float4(t.c[0][r], t.c[1][r], t.c[2][r], t.c[3][r]);
                 if (row >= g.nRowsY) continue;
                 if (FULL) *reinterpret_cast<float4*>(Y + (long long)row * g.y_row) = v;
-                else store4_bounded(Y + (long long)row * g.y_row, v, nValid);
+                else if (a.scalarStores) {
+                    float* q = Y + (long long)row * g.y_row;
+                    q[0] = v.x; if (nValid > 1) q[1] = v.y; if (nValid > 2) q[2] = v.z; if (nValid > 3) q[3] = v.w;
+                } else store4_bounded(Y + (long long)row * g.y_row, v, nValid);
             }
         }
     };
@@ -191,10 +198,15 @@ __global__ __launch_bounds__(128, 1) void band_gemm2_kernel(GemmArgs a)
 void launch_band_gemm(const BandGemmLaunch& g)
 {
     if (g.N <= 0 || g.nInst <= 0) return;
-    if ((g.x_row | g.y_row | g.x_band | g.y_band | g.x_inst | g.y_inst) & 3) SAF_FATAL("band gemm: strides must be multiples of 4 floats");
-    if ((((uintptr_t)g.X) | ((uintptr_t)g.Y)) & 15) SAF_FATAL("band gemm: operands must be 16-byte aligned");
+    if ((g.x_row | g.x_band | g.x_inst) & 3) SAF_FATAL("band gemm: the strides of X must be multiples of 4 floats");
+    if (((uintptr_t)g.X) & 15) SAF_FATAL("band gemm: X must be 16-byte aligned");
+    /* an output that is not 16-byte aligned or whose strides are not multiples of 4 floats (a caller's block at an odd offset)
+     * is written with 4-byte stores by the bounded variant of the one-term kernel */
+    const bool yOdd = ((g.y_row | g.y_band | g.y_inst) & 3) != 0 || (((uintptr_t)g.Y) & 15) != 0;
+    if (yOdd && g.nTerms != 1) SAF_FATAL("band gemm: the two-term form needs a 16-byte aligned output with strides that are multiples of 4 floats");
     GemmArgs a;
     a.g = g;
+    a.scalarStores = yOdd ? 1 : 0;
     a.nColTiles = (g.N + 127) / 128;
     a.unitsPerInst = g.nBands * a.nColTiles;
     /* as many units per workgroup as it takes for the whole launch to be resident at once (1 wave per SIMD on
@@ -210,7 +222,7 @@ void launch_band_gemm(const BandGemmLaunch& g)
         if (g.N % 128 != 0) SAF_FATAL("band gemm: the two-term form needs N to be a multiple of 128");
         hipLaunchKernelGGL(band_gemm2_kernel, grid, dim3(128), 0, stream(), a);
     } else if (g.nTerms != 1) SAF_FATAL("band gemm: 1 or 2 terms");
-    else if (g.N % 128 == 0) hipLaunchKernelGGL(band_gemm_kernel<true>, grid, dim3(128), 0, stream(), a);
+    else if (g.N % 128 == 0 && !yOdd) hipLaunchKernelGGL(band_gemm_kernel<true>, grid, dim3(128), 0, stream(), a);
     else                     hipLaunchKernelGGL(band_gemm_kernel<false>, grid, dim3(128), 0, stream(), a);
     HIP_CHECK(hipGetLastError());
 }
@@ -612,6 +624,59 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     enc_frame<false, true>(a.e, a.frameBase + blockIdx.y, blockIdx.z);
 }
 
+/* Do two sets of F-float segments  base + i0 s0 + i1 s1 + i2 s2  (0 <= ik < nk, any sign of the strides) share a float?
+ * 1. extents (anchored at the right end for negative strides) apart: no.  2. the same strides on both sides: the sets are
+ * translates of one lattice, so they meet iff the distance of the bases is within F of a lattice difference — (2 n0 - 1)(2 n1 - 1)
+ * candidates, the third index solved for.  3. otherwise: sort the segments of both sets by start and sweep (the verdict for the
+ * last shape seen is kept: a caller repeats its layout).  Exact in all three. */
+struct StridedSet { const float* base; long long s[3]; int n[3]; int F; };
+static bool strided_sets_overlap(const StridedSet& a, const StridedSet& b)
+{
+    auto lo_hi = [](const StridedSet& x, long long& lo, long long& hi) {
+        lo = 0; hi = x.F;
+        for (int k = 0; k < 3; k++) { const long long ext = (long long)(x.n[k] - 1) * x.s[k]; if (ext < 0) lo += ext; else hi += ext; }
+    };
+    long long alo, ahi, blo, bhi;
+    lo_hi(a, alo, ahi); lo_hi(b, blo, bhi);
+    const long long d = b.base - a.base;                                  /* floats */
+    if (d + bhi <= alo || ahi <= d + blo) return false;
+    if (a.s[0] == b.s[0] && a.s[1] == b.s[1] && a.s[2] == b.s[2]) {
+        /* a-segment (i) meets b-segment (j) iff |d + (j - i) . s| < F */
+        for (long long d0 = -(a.n[0] - 1); d0 <= b.n[0] - 1; d0++)
+            for (long long d1 = -(a.n[1] - 1); d1 <= b.n[1] - 1; d1++) {
+                const long long r = d + d0 * a.s[0] + d1 * a.s[1];
+                if (a.s[2] == 0) { if (r > -a.F && r < a.F) return true; continue; }
+                const long long q = -r / a.s[2];
+                for (long long d2 = q - 1; d2 <= q + 1; d2++) {
+                    if (d2 < -(a.n[2] - 1) || d2 > b.n[2] - 1) continue;
+                    const long long v = r + d2 * a.s[2];
+                    if (v > -a.F && v < a.F) return true;
+                }
+            }
+        return false;
+    }
+    static std::mutex mtx;
+    static StridedSet lastA{}, lastB{}; static bool lastV = false, have = false;
+    std::lock_guard<std::mutex> lk(mtx);
+    if (have && !memcmp(&lastA, &a, sizeof(a)) && !memcmp(&lastB, &b, sizeof(b))) return lastV;
+    std::vector<std::pair<long long, int>> seg;
+    seg.reserve((size_t)a.n[0] * a.n[1] * a.n[2] + (size_t)b.n[0] * b.n[1] * b.n[2]);
+    for (int w = 0; w < 2; w++) {
+        const StridedSet& x = w ? b : a;
+        for (int i = 0; i < x.n[0]; i++) for (int j = 0; j < x.n[1]; j++) for (int k = 0; k < x.n[2]; k++)
+            seg.emplace_back((w ? d : 0) + i * x.s[0] + j * x.s[1] + k * x.s[2], w);
+    }
+    std::sort(seg.begin(), seg.end());
+    bool v = false;
+    long long endOf[2] = { LLONG_MIN, LLONG_MIN };                        /* furthest end seen so far, per set */
+    for (const auto& sg : seg) {
+        if (sg.first < endOf[sg.second ^ 1]) { v = true; break; }
+        if (sg.first + a.F > endOf[sg.second]) endOf[sg.second] = sg.first + a.F;
+    }
+    lastA = a; lastB = b; lastV = v; have = true;
+    return v;
+}
+
 void launch_enc_gemm(const EncLaunch& e)
 {
     if (e.nFrames <= 0 || e.nInst <= 0) return;
@@ -619,17 +684,15 @@ void launch_enc_gemm(const EncLaunch& e)
     if ((((uintptr_t)e.in) | ((uintptr_t)e.out)) & 15) SAF_FATAL("ambi_enc: sample buffers must be 16-byte aligned");
     {
         /* in-place use is not possible: within one launch the workgroup of block f writes output block f while the workgroup
-         * of block f + 1 (and the state-save block) reads input block f */
-        auto ext = [&](long long s_inst, long long s_frame, long long s_ch, int rows) {
-            auto a = [](long long v) { return v < 0 ? -v : v; };
-            return (long long)(e.nInst - 1) * a(s_inst) + (long long)(e.nFrames - 1) * a(s_frame) + (long long)(rows > 0 ? rows - 1 : 0) * a(s_ch) + e.F;
-        };
+         * of block f + 1 (and the state-save block) reads input block f.  What is forbidden is an input segment [p, p + F) and an
+         * output segment sharing a float — not merely overlapping extents: in = t[:, 0], out = t[:, 1] of one [blocks][2][ch][F]
+         * tensor, or an [inst][chIn + chOut][F] workspace, are disjoint although their extents interleave. */
         const int rowsIn = e.rowsIn > 0 && e.rowsIn < SAF_MAXCH ? e.rowsIn : SAF_MAXCH;       /* rows the kernels can touch (higher rows re-read the last one) */
         const int rowsOut = e.nOut < SAF_MAXCH ? e.nOut : SAF_MAXCH;
-        const float* i0 = e.in; const float* i1 = e.in + ext(e.in_inst, e.in_frame, e.in_ch, rowsIn);
-        const float* o0 = e.out; const float* o1 = e.out + ext(e.out_inst, e.out_frame, e.out_ch, rowsOut);
-        if (i0 < o1 && o0 < i1)
-            SAF_FATAL("encode GEMM (ambi_enc / rotator / beamformer *_process_dev, batch_process): input and output buffers overlap; the device entry points do not work in place");
+        const StridedSet si{ e.in, { e.in_inst, e.in_frame, e.in_ch }, { e.nInst, e.nFrames, rowsIn }, e.F };
+        const StridedSet so{ e.out, { e.out_inst, e.out_frame, e.out_ch }, { e.nInst, e.nFrames, rowsOut }, e.F };
+        if (strided_sets_overlap(si, so))
+            SAF_FATAL("encode GEMM (ambi_enc / rotator / beamformer *_process_dev, batch_process): an input block and an output block share memory; the device entry points do not work in place");
     }
     EncArgs a;
     a.e = e;
@@ -656,3 +719,11 @@ void launch_enc_gemm(const EncLaunch& e)
 }
 
 }  // namespace saf
+
+/* the overlap test of launch_enc_gemm, callable without a GPU (tests/test_lib_cpu.py compares it with brute force) */
+extern "C" __attribute__((visibility("default"))) int saf_hip_debug_segments_overlap(const float* a, long long a0, long long a1, long long a2, int an0, int an1, int an2,
+                                                                                       const float* b, long long b0, long long b1, long long b2, int bn0, int bn1, int bn2, int F)
+{
+    const saf::StridedSet sa{ a, { a0, a1, a2 }, { an0, an1, an2 }, F }, sb{ b, { b0, b1, b2 }, { bn0, bn1, bn2 }, F };
+    return saf::strided_sets_overlap(sa, sb) ? 1 : 0;
+}

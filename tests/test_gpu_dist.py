@@ -115,4 +115,5 @@ def test_bench_spawns_two_ranks_on_the_gpu_box():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["instances_per_gpu"] == 8
-    assert line["roofline"]["kernels_ms"]["afstft_eq"] > 0
+    km = line["roofline"]["kernels_ms"]
+    assert km.get("afstft_eq", 0) > 0 or km.get("afstft_eq_decode", 0) > 0

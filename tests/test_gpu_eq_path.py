@@ -163,6 +163,33 @@ def test_equaliser_path_batch_split_invariance_and_strides(saf, orc, path):
     saf.set_stream(None)
 
 
+def test_output_block_at_an_odd_offset_stays_on_the_equaliser_path(saf, orc, path):
+    """an output buffer that is not 16-byte aligned (one float into a tensor): the time-domain GEMM writes it with 4-byte stores, the
+    pipeline stays on the equaliser path, and the next aligned call continues the same stream"""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    path(1)
+    F, order, nF = 256, 5, 6
+    orders = band_orders(order, 3)
+    x = frames(910, nF * 36, F).reshape(1, nF, 36, F)
+    d_in = torch.from_numpy(x).cuda()
+    st = (nF * 36 * F, 36 * F, F)
+    g, o = make(saf.AmbiDec, F, order, 28, 3, 3, 1, 1, orders), make(orc.AmbiDec, F, order, 28, 3, 3, 1, 1, orders)
+    bt = saf.AmbiDecBatch([g], nF)
+    buf = torch.zeros(1 + nF * 49 * F, device="cuda")
+    so = (nF * 49 * F, 49 * F, F)
+    bt.process_ptr(d_in.data_ptr(), st, buf[1:].data_ptr(), so, 3)                    # odd offset
+    assert bt.lastPath() == 1
+    out2 = torch.zeros(1, 3, 49, F, device="cuda")
+    bt.process_ptr(d_in[:, 3:].data_ptr(), st, out2.data_ptr(), (3 * 49 * F, 49 * F, F), 3)      # aligned again
+    torch.cuda.synchronize()
+    assert bt.lastPath() == 1
+    yo = np.stack([o.process(x[0, f], 49) for f in range(nF)])
+    y = np.concatenate([buf[1:1 + 3 * 49 * F].cpu().numpy().reshape(3, 49, F), out2.cpu().numpy()[0]])
+    assert relrms(y, yo) < 3e-6
+    saf.set_stream(None)
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_batch_member_reinitialised_mid_stream(saf, orc, path, mode):
     """One member of a live batch gets another decoder (setDecMethod + initCodec) between two calls: its filterbank restarts from

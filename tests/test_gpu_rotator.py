@@ -84,4 +84,15 @@ def test_rotator_order0_and_device_entry(saf, orc):
     torch.cuda.synchronize()
     yo = np.concatenate(yo, 1)
     assert maxabs(d_out.cpu().numpy(), yo) < 2e-6
+    # input and output interleaved in ONE tensor [2][nSH][time] viewed per channel pair — extents overlap, no block shares memory
+    # with another (the exact overlap test of launch_enc_gemm: an extent test would abort here)
+    g2, o2 = saf.Rotator(F), orc.Rotator(F)
+    for r in (g2, o2):
+        r.init(48000); r.setOrder(order); r.setYaw(-20.0)
+    t = torch.zeros(nSH, 2, nF * F, device="cuda")
+    t[:, 0] = torch.from_numpy(x[:, :nF * F]).cuda()
+    g2.process_dev(t[:, 0].data_ptr(), (F, 2 * nF * F), nSH, t[:, 1].data_ptr(), (F, 2 * nF * F), nSH, nF)
+    torch.cuda.synchronize()
+    yo2 = np.concatenate([o2.process(np.ascontiguousarray(x[:, i * F:(i + 1) * F]), nSH) for i in range(nF)], 1)
+    assert maxabs(t[:, 1].cpu().numpy(), yo2) < 2e-6
     saf.set_stream(None)

@@ -128,3 +128,43 @@ def test_dvf_host_functions_known_answers(saf, orc):
         al, be = saf.doaToIpsiInteraural(az, el)
         alo, beo = orc.doaToIpsiInteraural(az, el)
         assert np.abs(al - alo).max() < 1e-4 and np.abs(be - beo).max() < 1e-4
+
+
+def test_encode_gemm_overlap_check_is_exact():
+    """launch_enc_gemm refuses calls whose input and output blocks share memory.  The test behind it must be exact for strided
+    views: interleaved but disjoint buffers (in = t[:, 0], out = t[:, 1] of one tensor; an [inst][chIn + chOut][F] workspace) are
+    legal, negative strides anchor the extent at the other end.  Compared with brute force on random shapes, all three branches
+    (extents apart / equal strides / different strides)."""
+    import ctypes as C
+    import random
+    from spatial_audio_framework_amd._lib import load
+    L = load()
+    fn = L.saf_hip_debug_segments_overlap
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] + [C.c_longlong] * 3 + [C.c_int] * 3 + [C.c_void_p] + [C.c_longlong] * 3 + [C.c_int] * 3 + [C.c_int]
+    base = 1 << 20
+
+    def brute(a, sa, na, b, sb, nb, F):
+        A = {a + i * sa[0] + j * sa[1] + k * sa[2] for i in range(na[0]) for j in range(na[1]) for k in range(na[2])}
+        B = {b + i * sb[0] + j * sb[1] + k * sb[2] for i in range(nb[0]) for j in range(nb[1]) for k in range(nb[2])}
+        return any(abs(p - q) < F for p in A for q in B)
+
+    def check(a, sa, na, b, sb, nb, F):
+        got = fn(base * 4 + a * 4, *sa, *na, base * 4 + b * 4, *sb, *nb, F)
+        assert bool(got) == brute(a, sa, na, b, sb, nb, F), (a, sa, na, b, sb, nb, F)
+    F = 8
+    # one [blocks][2][ch][F] tensor: in = t[:, 0], out = t[:, 1]
+    check(0, (0, 2 * 4 * F, F), (1, 5, 4), 4 * F, (0, 2 * 4 * F, F), (1, 5, 4), F)
+    # an [inst][chIn + chOut][F] workspace
+    check(0, (7 * F, 0, F), (3, 1, 4), 4 * F, (7 * F, 0, F), (3, 1, 3), F)
+    # the same with the output one float too early: shares memory
+    check(0, (7 * F, 0, F), (3, 1, 4), 4 * F - 1, (7 * F, 0, F), (3, 1, 3), F)
+    # in place
+    check(0, (64 * F, 16 * F, F), (2, 4, 16), 0, (64 * F, 16 * F, F), (2, 4, 16), F)
+    rnd = random.Random(3)
+    for _ in range(400):
+        na = (rnd.randint(1, 3), rnd.randint(1, 4), rnd.randint(1, 4)); nb = (rnd.randint(1, 3), rnd.randint(1, 4), rnd.randint(1, 4))
+        sa = tuple(rnd.choice((-1, 1)) * rnd.choice((0, F, 2 * F, 3 * F, 5 * F, 12 * F, 13 * F + 4)) for _ in range(3))
+        sb = sa if rnd.random() < 0.5 else tuple(rnd.choice((-1, 1)) * rnd.choice((F, 2 * F, 4 * F, 7 * F, 12 * F)) for _ in range(3))
+        check(rnd.randint(-40, 40) * 4, sa, na, rnd.randint(-40, 40) * 4 + rnd.choice((0, 0, 1, 3)), sb, nb, F)
+
