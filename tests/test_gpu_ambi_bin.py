@@ -8,7 +8,7 @@ forms are checked in tests/test_oracle_cpu.py.  Tolerance: 1e-5 relative RMS on 
 import numpy as np
 import pytest
 
-from util import frames, relrms, maxabs, synth_hrirs
+from util import frames, relrms, maxabs, synth_hrirs, ulp_perturb, oracle_sensitivity
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -46,7 +46,14 @@ def test_decoder_matrices_vs_oracle(saf, orc, hrirs, method, order, diffm, maxre
     w = orc.getVoronoiWeights(d)
     Dg = saf.getBinauralAmbiDecoderMtx(H, d, method, order, fv, None, w, diffm, maxre)
     Do = orc.getBinauralAmbiDecoderMtx(H, d, method, order, fv, None, w, diffm, maxre)
-    assert relrms(Dg, Do) < (2e-5 if method == 5 else TOL)      # MagLS chains atan2 of the previous band through 12 bands
+    bound = TOL
+    if method == 5:
+        # MagLS chains atan2 of the previous band's result through the bands: its bound is K x what the ORACLE's own matrices move
+        # when the HRTFs move by one unit in the last place (floored at 1e-5), not a constant
+        sens = oracle_sensitivity(lambda sd: orc.getBinauralAmbiDecoderMtx(ulp_perturb(H, sd), d, method, order, fv, None, w, diffm, maxre), Do, relrms)
+        bound = max(TOL, 4.0 * sens)
+        print(f"MagLS order {order}: |hip - oracle| {relrms(Dg, Do):.2e}, oracle 1-ulp sensitivity {sens:.2e}")
+    assert relrms(Dg, Do) < bound
 
 
 @pytest.mark.parametrize("method,preproc,order,norm", [(5, 2, 3, 2), (1, 2, 2, 1), (2, 4, 1, 3), (3, 1, 4, 2), (4, 3, 7, 1)])
@@ -61,7 +68,8 @@ def test_ambi_bin_vs_oracle(saf, orc, hrirs, method, preproc, order, norm):
         a.setNormType(norm); a.setChOrder(2 if (order == 1 and norm == 3) else 1)
         a.setEnableDiffuseMatching(1 if method == 2 else 0)
         a.init(48000); a.initCodec()
-    assert relrms(g.decMtx(nSH), o.decMtx(nSH)) < (3e-5 if method == 5 else TOL)
+    print(f"ambi_bin method {method}: decoder matrices |hip - oracle| {relrms(g.decMtx(nSH), o.decMtx(nSH)):.2e}")
+    assert relrms(g.decMtx(nSH), o.decMtx(nSH)) < TOL
     x = frames(40 + order, nSH, 12 * F)
     num = den = 0.0
     for b in range(12):
@@ -75,7 +83,8 @@ def test_ambi_bin_vs_oracle(saf, orc, hrirs, method, preproc, order, norm):
         yg, yo = g.process(blk, 3), o.process(blk, 3)
         assert np.all(yg[2] == 0)
         num += float(((yg[:2] - yo[:2]) ** 2).sum()); den += float((yo[:2] ** 2).sum())
-    assert den > 1e-3 and (num / den) ** 0.5 < (3e-5 if method == 5 else TOL)
+    print(f"ambi_bin method {method}: ears |hip - oracle| {(num / den) ** 0.5:.2e}")
+    assert den > 1e-3 and (num / den) ** 0.5 < TOL
 
 
 def test_ambi_bin_device_entry_and_zero_rules(saf, orc, hrirs):
@@ -94,7 +103,8 @@ def test_ambi_bin_device_entry_and_zero_rules(saf, orc, hrirs):
         g.process_dev(d_in.data_ptr() + off, (F, 2 * nF * F), nSH, d_out.data_ptr() + off, (F, 2 * nF * F), nF)
     torch.cuda.synchronize()
     yo = np.concatenate([o.process(np.ascontiguousarray(x[:, b * F:(b + 1) * F])) for b in range(2 * nF)], 1)
-    assert relrms(d_out.cpu().numpy(), yo) < 2e-5
+    print(f"ambi_bin device entry: |hip - oracle| {relrms(d_out.cpu().numpy(), yo):.2e}")
+    assert relrms(d_out.cpu().numpy(), yo) < TOL
     saf.set_stream(None)
     g.setEnableMaxRE(0)                                      # codec no longer initialised -> zeros until initCodec
     assert not g.process(x[:, :F], 2).any()
@@ -138,7 +148,8 @@ def test_decoder_filters_vs_oracle_and_against_the_matrix(saf, orc, hrirs, metho
     fg = saf.getBinauralAmbiDecoderFilters(H, d, fftSize, 48000.0, method, order, None, w, 0, 1)
     fo = orc.getBinauralAmbiDecoderFilters(H, d, fftSize, 48000.0, method, order, None, w, 0, 1)
     assert fg.shape == (2, (order + 1) ** 2, fftSize) and np.abs(fo).max() > 1e-3
-    assert relrms(fg, fo) < (3e-5 if method == 5 else TOL)
+    print(f"decoder filters method {method}: |hip - oracle| {relrms(fg, fo):.2e}")
+    assert relrms(fg, fo) < TOL
     fv = (np.arange(fftSize // 2 + 1) * 48000.0 / fftSize).astype(np.float32)
     D = saf.getBinauralAmbiDecoderMtx(H, d, method, order, fv, None, w, 0, 1)            # [bins][2][nSH]
     back = np.transpose(np.fft.rfft(fg.astype(np.float64), axis=2), (2, 0, 1))

@@ -39,6 +39,24 @@ def maxabs(a, b):
     return float(np.abs(np.asarray(a) - np.asarray(b)).max())
 
 
+def ulp_perturb(a, seed, ulps=1.0):
+    """`a` (float32 / complex64) with every component moved by up to `ulps` units in its last place, random size and sign: the
+    change any reordering of float32 operations upstream may cause"""
+    rng = np.random.default_rng(seed)
+    a = np.asarray(a)
+    eps = np.float64(2.0 ** -23) * ulps
+    if np.iscomplexobj(a):
+        return (a.real * (1 + eps * rng.uniform(-1, 1, a.shape)) + 1j * a.imag * (1 + eps * rng.uniform(-1, 1, a.shape))).astype(a.dtype)
+    return (a * (1 + eps * rng.uniform(-1, 1, a.shape))).astype(a.dtype)
+
+
+def oracle_sensitivity(run, ref, metric, seeds=(11, 12, 13)):
+    """How far the ORACLE's own output moves (in `metric(out, ref)`) when its input moves by one unit in the last place:
+    run(seed) returns the oracle's output on an input perturbed with that seed, `ref` is its output on the exact input.
+    A bound on |library - oracle| for an ill-conditioned function is a multiple of this, not a constant picked by hand."""
+    return max(metric(run(sd), ref) for sd in seeds)
+
+
 def canon_faces(F):
     """Canonical form of a face list: each triangle's vertices sorted, rows sorted."""
     F = np.sort(np.asarray(F, np.int64), axis=1)
