@@ -43,6 +43,7 @@ ALG_BYTES_PER_FRAME = {            # algorithmic bytes of each ke
     "afstft_eq": 2 * NCH * FRAME * 4,                             # samples in + equalised SH signals out (one dense decoder)
     "band_gemm": 2 * NCH * FRAME * 4,                             # equalised SH signals in + loudspeaker samples out
     "dec_stream": 2 * NCH * FRAME * 4,                            # the same product as the kernel that runs beside the equaliser
+    "afstft_eq_coop": 2 * NCH * FRAME * 4,                        # equaliser and decode in one launch, z handed over on chip (samples in, samples out)
     "afstft_eq_decode": 2 * NCH * FRAME * 4,                      # small launches: equaliser and decode in one launch (samples in, samples out)
     "afstft_analysis": NCH * FRAME * 4 + 133 * NCH * 4 * 8,      # transform path: samples in + spectra out
     "afstft_synthesis": 133 * NCH * 4 * 8 + NCH * FRAME * 4,     # transform path: spectra in + samples out
@@ -379,7 +380,7 @@ def run_rank(args):
         return {"value": round(world * nI * nF * args.steps / dt, 1), "unit": "frames/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
                 "kernels_ms": {k: round(v[0], 5) for k, v in per.items()}, "note": note}
 
-    EQK = ("afstft_eq", "afstft_eq_decode", "dec_stream", "band_gemm")
+    EQK = ("afstft_eq", "afstft_eq_coop", "afstft_eq_decode", "dec_stream", "band_gemm")
     torch.cuda.synchronize()                    # the synthetic inputs were produced on torch's stream, the library launches on its own
     elapsed, general_kernels = timed_region(batch, args.path_mode, EQK if args.path_mode else ("afstft_analysis", "band_gemm", "afstft_synthesis"), args.steps, args.warmup)
     extra = {}

@@ -40,6 +40,7 @@ static int g_ambi_dec_time_domain = []() { const char* e = getenv("SAF_HIP_AMBI_
  * MI355X (profiles/r03_overlap_experiment.txt): side by side the two kernels take as long as one after the other (the pair is
  * bound by the 9.8 GB it moves through HBM, not by the vector or matrix pipes), and publishing z per workgroup (an agent-scope
  * release = L2 write-back per workgroup) costs the equaliser kernel another 0.4 ms. */
+static unsigned g_coop_target_bias = 0;   /* tests: a bias that no counter reaches makes every cooperative decode give up (the re-run launches must then produce the block) */
 static int g_ambi_dec_overlap = []() { const char* e = getenv("SAF_HIP_AMBI_DEC_OVERLAP"); return e ? atoi(e) : 0; }();
 
 static inline void sleep_ms(int ms) { std::this_thread::sleep_for(std::chrono::milliseconds(ms)); }
@@ -104,7 +105,11 @@ struct DecPipeline {
     DevBuf<unsigned> eqDone;        /* [nInst] equaliser workgroups finished, monotonic over the publishing launches */
     DevBuf<int> eqErr;              /* [2] see DecStreamLaunch::err */
     unsigned eqDoneBase = 0;
-    int lastOverlap = 0;            /* 1: the last call ran the decode kernel beside the equaliser kernel */
+    int lastOverlap = 0;            /* 1: the last call ran the decode kernel beside the equaliser kernel; 3: inside it (cooperative form) */
+    DevBuf<float> coRing;           /* [nInst][64][ring slots][16 hops][128] z of the cooperative form: written and read inside ONE launch */
+    DevBuf<unsigned> coCnt;         /* [nInst][coNSub] waves that have stored their z of a sub-chunk (zeroed before every launch) */
+    int coNSub = 0;
+    DevBuf<long long> coDbg;        /* -DEQ_COOP_CHECK builds: the first out-of-range access of the cooperative form */
     int zsynPar = 0, eqD = 1;
     std::vector<char> eqDirty, eqTwo;        /* per instance: tables stale; the two decoders are different matrices */
     std::vector<unsigned long long> eqTwoEpoch;
@@ -477,6 +482,36 @@ struct DecPipeline {
             /* Small launches (the one-block host-pointer call is bound by launches, not by the chip): equaliser and decode in ONE
              * launch — the decode workgroups ride behind the channel workgroups and wait on the instance's counter. */
             static const int fuseSmall = []() { const char* v = getenv("SAF_HIP_AMBI_DEC_ONE_LAUNCH"); return v ? atoi(v) : 1; }();
+            /* Optional (setOverlap(3)): the decode INSIDE the equaliser launch.  The 64 channel workgroups of an instance hand
+             * their z to each other through a small ring (write-through stores, per-sub-chunk counters) and each decodes its 32
+             * columns of every sub-chunk: z never takes the round trip through zbuf.  A workgroup that gives up waiting sets
+             * errPin and the two guarded launches behind recompute the call the ordinary way (the histories are still unflipped). */
+            if (g_ambi_dec_overlap == 3 && eqD == 1 && nSH == SAF_MAXCH && nLS == 64 && H % 16 == 0 &&
+                out_frame < (1ll << 31) && out_ch < (1ll << 29) && out_frame >= 0 && out_ch >= 0) {
+                const int nSub = H / 16;
+                if (coRing.p == nullptr) coRing.alloc((size_t)nInst * SAF_MAXCH * eq_coop_ring_slots() * 16 * SAF_HOP);
+                if (coNSub < nSub) { coCnt.alloc((size_t)nInst * nSub); coNSub = nSub; }
+                errPin.ensure(1);
+                HIP_CHECK(hipMemsetAsync(coCnt.p, 0, (size_t)nInst * coNSub * sizeof(unsigned), stream()));
+                EqCoop c{};
+                c.ring = coRing.p; c.cnt = coCnt.p; c.target = 2u * SAF_MAXCH + g_coop_target_bias; c.nSub = coNSub;
+                c.Y = d_out; c.y_inst = out_inst; c.y_frame = (int)out_frame; c.y_row = (int)out_ch; c.nRowsY = nLS; c.F = F; c.T = T;
+                c.Mfrag = Mfrag.p; c.m_inst = 2 * 64 * 64; c.err = errPin.p; c.giveUps = eqErr.p ? eqErr.p + 1 : nullptr;
+#ifdef EQ_COOP_CHECK
+                if (!coDbg.p) coDbg.alloc(8);
+                c.dbg = coDbg.p; c.ringBytes = (long long)coRing.n * 4; c.cntBytes = (long long)coCnt.n * 4; c.mBytes = (long long)Mfrag.n * 4;
+                c.yBytes = ((long long)(nInst - 1) * out_inst + (long long)(nFrames - 1) * out_frame + (long long)(nLS - 1) * out_ch + F) * 4;
+#endif
+                if (launch_eq_coop(q, c)) {
+                    EqLaunch q2 = q; q2.runFlag = errPin.p;
+                    launch_eq(q2);                                      /* both leave at once unless a workgroup gave up */
+                    gn.runFlag = errPin.p;
+                    launch_band_gemm(gn);
+                    st.anaPar ^= 1; zsynPar ^= 1;
+                    synDomain = DOM_SH; lastPath = 1; lastOverlap = 3;
+                    return;
+                }
+            }
             if (fuseSmall && !overlap) {
                 EqDecodeTail t{};
                 t.Y = d_out; t.y_inst = out_inst; t.y_frame = out_frame; t.y_row = out_ch; t.Mfrag = Mfrag.p; t.m_inst = 2 * 64 * 64;
@@ -916,7 +951,19 @@ int saf_hip_ambi_dec_batch_decodeGiveUps(void* const hBatch)
     HIP_CHECK(hipMemcpy(v, b->eqErr.p, sizeof(v), hipMemcpyDeviceToHost));
     return v[1];
 }
-void saf_hip_ambi_dec_setOverlap(int mode) { g_ambi_dec_overlap = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+void saf_hip_ambi_dec_setOverlap(int mode) { g_ambi_dec_overlap = mode < 0 ? 0 : (mode > 3 ? 3 : mode); }
+__attribute__((visibility("default"))) long long saf_hip_debug_batch_fetch(void* const hBatch, int which, float* dst, long long n)
+{   /* tests: the equaliser output buffer (0) or the cooperative form's ring (1), copied to the host */
+    DecPipeline* b = (DecPipeline*)hBatch;
+    HIP_CHECK(hipStreamSynchronize(stream()));
+    const float* src = which == 0 ? b->zbuf.p : which == 1 ? b->coRing.p : (const float*)b->coDbg.p;
+    const long long have = (long long)(which == 0 ? b->zbuf.n : which == 1 ? b->coRing.n : b->coDbg.n * 2);
+    if (!src) return 0;
+    if (n > have) n = have;
+    HIP_CHECK(hipMemcpy(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return n;
+}
+__attribute__((visibility("default"))) void saf_hip_debug_coop_target_bias(unsigned bias) { g_coop_target_bias = bias; }
 int saf_hip_ambi_dec_getOverlap(void) { return g_ambi_dec_overlap; }
 int saf_hip_ambi_dec_lastPath(void* const hAmbi) { AmbiDec* p = (AmbiDec*)hAmbi; return p->pipe ? p->pipe->lastPath : -1; }
 void saf_hip_ambi_dec_batch_process(void* const hBatch,

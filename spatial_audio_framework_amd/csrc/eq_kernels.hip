@@ -56,7 +56,9 @@ namespace saf {
 
 struct EqArgs { EqLaunch e; const float* win; const float2* twJ; const float2* tw256; int chunk; unsigned long long* stamps;
                 unsigned* done; int prio;         /* publishing launches: [nInst] counters of finished workgroups (see the end of the kernel) */
-                EqDecodeTail dec; unsigned target; };   /* MODE 2: the decode blocks behind the channel blocks of every instance */
+                EqDecodeTail dec; unsigned target;      /* MODE 2: the decode blocks behind the channel blocks of every instance */
+                EqCoop co;                              /* MODE 3: the cooperative decode (below) */
+                const int* runFlag; };                  /* MODE 0, when set: the launch does nothing unless *runFlag != 0 (the re-run behind MODE 3) */
 #ifdef EQ_STAMPS        /* diagnostic build only: cycles per phase of every 64th workgroup (tools/eq_stamps.py) */
 #define STAMP(i) do { if (stampOn && lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += t_ - stampT; stampT = t_; } } while (0)
 #else
@@ -138,6 +140,32 @@ __device__ __forceinline__ void decode_tail(const EqLaunch& e, const EqDecodeTai
     }
 }
 
+/* MODE 3 — the decode INSIDE the equaliser launch, z never crossing HBM (order 7: 64 SH channels, 64 loudspeakers, one dense decoder).
+ * The 64 channel workgroups of an instance hand their z to each other through a small ring (EQF_R sub-chunks of 16 hops per channel)
+ * and each of them computes 1/64 of the instance's decode per sub-chunk: workgroup ch owns columns [32 ch, 32 ch + 32) of the
+ * sub-chunk's 2048 samples — wave w the loudspeaker rows 32 w .. 32 w + 31 — as 32 k-pair steps of v_mfma_f32_32x32x2_f32 whose B
+ * operand is one 4-byte load per lane (row = SH channel 2 s + (lane >> 5) of the ring, 128 contiguous bytes per half wave).
+ *   iteration it:  [filterbank of sub-chunk it, z re-packed through the dead frame slots into 16-byte WRITE-THROUGH stores to ring
+ *                  slot it % R]  [publish sub-chunk it - 1: its stores are a whole iteration old, s_waitcnt vmcnt(16) lets only
+ *                  the next input prefetch stay in flight; one counter add per wave]  [decode of sub-chunk it - L: poll its
+ *                  counter (128 arrivals), barrier, write-through-coherent loads (sc1), MFMAs, plain stores of the output block]
+ * Hand-over form: MI355X_MICROARCH.md "Hand-offs measured with sc1 loads in place of the acquire", third row (every 128-byte line
+ * written whole by ONE 16-byte-per-lane sc1 store instruction of one wave; every storing wave adds to the counter after its wait;
+ * a 4-byte sc1 poll; a workgroup barrier between the poll and every load; 4-byte sc1 loads).  No L2 write-back, no L1 invalidate.
+ * Ring reuse needs no second signal: a writer at iteration it has seen all-published(it - 1 - L), i.e. every workgroup is past
+ * the reads of sub-chunk it - 2 L - 1; with R >= 2 L + 1 the slot it overwrites (sub-chunk it - R) is no longer read.
+ * All 64 workgroups of an instance wait for each other, so they must be resident together: they are consecutive blocks of an
+ * in-order dispatch (observed, not promised: a poll that is not answered within ~0.2 s gives up, sets the host-visible flag, and the
+ * guarded re-run launches behind this one — the plain kernel and the stand-alone GEMM — recompute the step from the untouched
+ * input state). */
+#ifndef EQF_R
+#define EQF_R 8
+#endif
+#ifndef EQF_L
+#define EQF_L 2
+#endif
+static_assert(EQF_R >= 2 * EQF_L + 1, "ring too short for the decode lag");
+
 template <int D, int MODE>
 __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING void afstft_eq_kernel(EqArgs g)      /* (MODE 2: small launches, occupancy does not matter) */
 {
@@ -159,13 +187,14 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
 
     const EqLaunch& e = g.e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr bool PUBLISH = MODE != 0;
     const int ch = blockIdx.x, inst = blockIdx.y;
     if (MODE == 2) {
         __shared__ int s_ok;
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) __hip_atomic_store(g.dec.err, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int)blockIdx.x >= e.nCh) { decode_tail<D>(e, g.dec, g.done, g.target, s_ring, s_out1, &s_ok, inst, (int)blockIdx.x - e.nCh); return; }
     }
+    if (MODE == 0 && g.runFlag != nullptr && *g.runFlag == 0) return;      /* re-run launch behind MODE 3: nothing to repair */
+    if (MODE == 3 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) __hip_atomic_store(g.co.err, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const int T = e.hopsPerFrame;
     /* Beside the decode kernel (launch_dec_stream) the waves of this kernel share their SIMDs with MFMA waves that were
      * dispatched earlier: arbitration is by priority, then age, so at equal priority the MFMA wave takes every issue slot it
@@ -318,6 +347,92 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
     unsigned long long stampAcc[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, stampT = __builtin_amdgcn_s_memtime();
 #endif
 
+    /* ---- MODE 3: ring, counters, this workgroup's slice of the decode ---- */
+#ifdef EQ_COOP_CHECK
+    auto co_ok = [&](int kind, gbase_t base, unsigned off, int bytes, const void* lo, long long extent, int a, int b) -> bool {
+        const long long o = (long long)((unsigned long long)base - (unsigned long long)lo) + off;
+        if (o >= 0 && o + bytes <= extent) return true;
+        if (g.co.dbg && atomicCAS(reinterpret_cast<unsigned long long*>(g.co.dbg), 0ull, (unsigned long long)kind) == 0ull) {
+            g.co.dbg[1] = o; g.co.dbg[2] = extent; g.co.dbg[3] = inst; g.co.dbg[4] = ch; g.co.dbg[5] = a; g.co.dbg[6] = b; g.co.dbg[7] = tid;
+        }
+        return false;
+    };
+#define CO_OK(kind, base, off, bytes, lo, extent, a, b) co_ok(kind, base, off, bytes, lo, extent, a, b)
+#else
+#define CO_OK(kind, base, off, bytes, lo, extent, a, b) true
+#endif
+    __shared__ int s_coop[2];
+    bool coDead = false;                                     /* a poll gave up: no more decodes (the re-run launches recompute the step) */
+    const int coHl = ch >> 2, coSo = (ch & 3) * 32;          /* this workgroup's 32 columns of a sub-chunk: hop coHl, samples coSo .. coSo + 31 */
+    auto co_publish = [&](int k) {                           /* this wave's z of sub-chunk k is in memory (the caller has waited for its stores) */
+        if (lane == 0 && CO_OK(1, uniform_gbase(g.co.cnt + (long long)inst * g.co.nSub + k), 0u, 4, g.co.cnt, g.co.cntBytes, k, 0))
+            __hip_atomic_fetch_add(g.co.cnt + (long long)inst * g.co.nSub + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto co_decode = [&](int gsub) {                         /* out[:, slice] of sub-chunk gsub = M z[:, slice] */
+        int ok = 1;
+        if (lane == 0 && !coDead) {
+            ok = 0;
+            const unsigned* c = g.co.cnt + (long long)inst * g.co.nSub + gsub;
+            for (int itp = 0; itp < 400000 && CO_OK(2, uniform_gbase(c), 0u, 4, g.co.cnt, g.co.cntBytes, gsub, 0); itp++) {          /* bounded: ~0.2 s */
+                const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(v - g.co.target) >= 0) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+        if (lane == 0) s_coop[wv] = ok;
+        lds_barrier();
+        const bool bothOk = s_coop[0] != 0 && s_coop[1] != 0;
+        lds_barrier();                                       /* (s_coop is rewritten by the next decode) */
+        if (!bothOk || coDead) {
+            if (!coDead && tid == 0) {
+                __hip_atomic_store(g.co.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (g.co.giveUps) atomicAdd(g.co.giveUps, 1);
+            }
+            coDead = true;
+            return;
+        }
+        int lq = lane;
+        asm volatile("" : "+v"(lq));                          /* (the lane offsets below are recomputed per decode: hoisted out of the sub-chunk loop they cost registers the filterbank needs) */
+        const int kh = lq >> 5, lr = lq & 31;
+        const int slot = gsub % EQF_R;
+        /* every access is  uniform base (scalar registers) + 32-bit lane offset: 64-bit addresses per lane for 32 + 32 + 16 accesses
+         * would not fit beside the filterbank state */
+        /* B operand: SH channel c = 2 s + kh of the ring, this workgroup's 32 columns */
+        const gbase_t zb = uniform_gbase(g.co.ring + ((long long)inst * SAF_MAXCH * EQF_R + slot) * (SUB * SAF_HOP) + coHl * SAF_HOP + coSo);
+        const unsigned zl = (unsigned)(kh * EQF_R * (SUB * SAF_HOP) + lr) * 4u;
+        const unsigned zstep = 2u * EQF_R * (SUB * SAF_HOP) * 4u;                 /* bytes between the row pairs of consecutive steps */
+        const gbase_t Af = uniform_gbase(g.co.Mfrag + (long long)inst * g.co.m_inst + wv * 2048);
+        const unsigned al = (unsigned)lq * 4u;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            /* half the operand rows in flight at a time (16 registers); the matrix fragments (L1 / L2 hits) in groups of four */
+            float b[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                b[i] = !CO_OK(3, zb + (16 * half + i) * zstep, zl, 4, g.co.ring, g.co.ringBytes, gsub, 16 * half + i) ? 0.0f :
+                       __hip_atomic_load(reinterpret_cast<const float __attribute__((address_space(1)))*>(zb + (16 * half + i) * zstep + zl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* global_load_dword sc1 */
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float a[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) a[i] = !CO_OK(4, Af + (16 * half + 4 * q + i) * 256u, al, 4, g.co.Mfrag, g.co.mBytes, gsub, 16 * half + 4 * q + i) ? 0.0f : gld<float>(Af + (16 * half + 4 * q + i) * 256u, al);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[4 * q + i], acc, 0, 0, 0);
+            }
+        }
+        const int hg = gsub * SUB + coHl, fr = hg / T;
+        const gbase_t Yb = uniform_gbase(g.co.Y + (long long)inst * g.co.y_inst + (long long)fr * g.co.y_frame + (hg - fr * T) * SAF_HOP + coSo + (long long)(wv * 32) * g.co.y_row);
+        const unsigned yl = (unsigned)(4 * kh * g.co.y_row + lr) * 4u;
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (CO_OK(5, Yb + (long long)((r & 3) + 8 * (r >> 2)) * g.co.y_row * 4, yl, 4, g.co.Y, g.co.yBytes, gsub, r))
+                gst<float>(Yb + (long long)((r & 3) + 8 * (r >> 2)) * g.co.y_row * 4, yl, acc[r]);
+    };
+    int coIt = 0;
+
     for (int s0 = hs; s0 < H; s0 += SUB) {
         const int n = min(SUB, H - s0);
         if (s0 > hs) {                                       /* the hops requested at the end of the previous iteration */
@@ -459,6 +574,12 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
 #pragma unroll
             for (int i = 0; i < SUB; i++) xin[9 + i] = ld_at(__builtin_amdgcn_readlane(offN, i));
         }
+        if (MODE == 3 && coIt > 0) {
+            /* publish sub-chunk coIt - 1: everything this wave issued before the 16 prefetch loads above has to be done — its ring
+             * stores are a whole iteration old */
+            if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            co_publish(coIt - 1);
+        }
         /* 5. 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0 + t is
          *    sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n] */
 #pragma unroll
@@ -482,7 +603,8 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
                         float acc = 0.0f;
 #pragma unroll
                         for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
-                        if (emit && u < nh) {      /* uniform 64-bit base (scalar registers) + 4 * tid */
+                        if (MODE == 3) lag_slot(uu)[tid] = acc;      /* the frame in this slot has been read: re-pack z through it (below) */
+                        else if (emit && u < nh) {      /* uniform 64-bit base (scalar registers) + 4 * tid */
                             gst<float>(uniform_gbase(zBase[d] + (long long)(s0 + uu) * SAF_HOP), (unsigned)(tid * 4), acc);
                         }
                     }
@@ -500,6 +622,31 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
                     }
                 }
             }
+        }
+        if (MODE == 3) {
+            /* z of this sub-chunk sits in the 16 lagged slots at [tid]; a wave re-reads its own 64 sample positions as 16-byte
+             * pieces (4 hops x 256 contiguous bytes per instruction) and stores them write-through: every 128-byte line of the ring
+             * is written whole by one store instruction */
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const gbase_t rb = uniform_gbase(g.co.ring + (((long long)inst * SAF_MAXCH + ch) * EQF_R + (coIt % EQF_R)) * (SUB * SAF_HOP) + 64 * wv);
+            int lq = lane;
+            asm volatile("" : "+v"(lq));
+            const unsigned rl = (unsigned)((lq >> 4) * SAF_HOP + 4 * (lq & 15)) * 4u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int hh = 4 * i + (lq >> 4);
+                const saf_v4f v = *reinterpret_cast<const saf_v4f*>(lag_slot(hh) + 64 * wv + 4 * (lq & 15));
+                const gbase_t q = rb + 4 * i * SAF_HOP * 4;
+                /* The compiler's hazard pass does not see through an inline instruction, so the two hazards of this store are
+                 * covered by hand: its scalar base comes from v_readfirstlane (a vector instruction writing a scalar register:
+                 * five wait states before a memory instruction may read it — without them the store can go out with the OLD
+                 * register contents, i.e. to a wild address), and a store of more than 8 bytes reads its data registers late
+                 * (two wait states before they may be rewritten). */
+                if (CO_OK(6, q, rl, 16, g.co.ring, g.co.ringBytes, coIt, i))
+                asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(rl), "v"(v), "s"(q) : "memory");
+            }
+            if (coIt >= EQF_L) co_decode(coIt - EQF_L);
+            coIt++;
         }
         STAMP(7);                                            /* prefetch wait + OLA + stores */
         pN = pN + SUB >= ERING ? pN + SUB - ERING : pN + SUB;
@@ -527,7 +674,13 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
             for (int i = 0; i < 9; i++) { h[i * 256 + tid] = gl[d][i]; h[i * 256 + 128 + tid] = gr[d][i]; }
         }
     }
-    if (PUBLISH) {
+    if (MODE == 3) {
+        /* drain: the last sub-chunk is published, then the decodes that lag behind */
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        co_publish(coIt - 1);
+        for (int gsub = coIt - EQF_L; gsub < coIt; gsub++) if (gsub >= 0) co_decode(gsub);
+    }
+    if (MODE == 1 || MODE == 2) {
         /* Publish this channel's z to the decode kernel that runs beside this one (launch_dec_stream, gemm_kernels.hip): every
          * wave's stores drained, workgroup barrier, agent-scope release (write-back of the XCD's L2), then the instance's counter
          * (MI355X_MICROARCH.md "Valid forms"; the consumer polls, acquires, then loads).  PUBLISH launches have no time chunks:
@@ -577,7 +730,7 @@ void launch_eq(const EqLaunch& e, unsigned* done)
     }
     const dim3 grid(e.nCh, e.nInst, (e.H + g.chunk - 1) / g.chunk);
     KernelTimer kt("afstft_eq");
-    g.done = done; g.target = 0; g.dec = EqDecodeTail{};
+    g.done = done; g.target = 0; g.dec = EqDecodeTail{}; g.co = EqCoop{}; g.runFlag = e.runFlag;
     { static const int p = []() { const char* v = getenv("SAF_HIP_EQ_PRIO"); return v ? atoi(v) : -1; }(); g.prio = p >= 0 ? p : (done != nullptr); }
     if (done) {
         if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, 1>), grid, dim3(128), 0, stream(), g);
@@ -613,7 +766,7 @@ bool launch_eq_decode(const EqLaunch& e, const EqDecodeTail& d, unsigned* done, 
     g.tw256 = g.twJ + 128;
     g.stamps = nullptr;
     g.chunk = e.H;
-    g.done = done; g.target = target; g.dec = d; g.prio = 0;
+    g.done = done; g.target = target; g.dec = d; g.prio = 0; g.co = EqCoop{}; g.runFlag = nullptr;
     const dim3 grid(e.nCh + nDec, e.nInst, 1);
     KernelTimer kt("afstft_eq_decode");
     if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, 2>), grid, dim3(128), 0, stream(), g);
@@ -621,6 +774,31 @@ bool launch_eq_decode(const EqLaunch& e, const EqDecodeTail& d, unsigned* done, 
     HIP_CHECK(hipGetLastError());
     return true;
 }
+
+bool launch_eq_coop(const EqLaunch& e, const EqCoop& c)
+{
+    if (e.H <= 0 || e.nInst <= 0) return true;
+    /* order 7 -> 64 loudspeakers, one dense decoder, whole sub-chunks; every lane stores 4 bytes of the output: no alignment rule */
+    if (e.D != 1 || e.nCh != SAF_MAXCH || c.nRowsY != 64 || e.H % SUB != 0 || c.nSub * SUB < e.H || c.T < 1 || SAF_HOP * c.T != c.F) return false;
+    const long long chSpan = (long long)(e.nChIn > 0 ? e.nChIn : 1) * e.in_ch;
+    const long long hopSpan = (long long)((e.H + e.hopsPerFrame - 1) / e.hopsPerFrame) * e.in_frame + (long long)e.hopsPerFrame * SAF_HOP;
+    if (e.in_ch < 0 || e.in_frame < 0 || e.H >= (1 << 22) || (chSpan + hopSpan) * 4 >= (1ll << 32))
+        SAF_FATAL("filterbank equaliser: one call spans more than 4 GiB of one instance's input, 2^22 hops or uses negative strides: split the call");
+    EqArgs g;
+    g.e = e;
+    g.win = dev_window(0, 0);
+    g.twJ = dev_twiddles();
+    g.tw256 = g.twJ + 128;
+    g.stamps = nullptr;
+    g.chunk = e.H;
+    g.done = nullptr; g.target = 0; g.dec = EqDecodeTail{}; g.prio = 0; g.co = c; g.runFlag = nullptr;
+    KernelTimer kt("afstft_eq_coop");
+    hipLaunchKernelGGL((afstft_eq_kernel<1, 3>), dim3(e.nCh, e.nInst, 1), dim3(128), 0, stream(), g);
+    HIP_CHECK(hipGetLastError());
+    return true;
+}
+
+int eq_coop_ring_slots() { return EQF_R; }
 
 }  // namespace saf
 

@@ -179,6 +179,7 @@ struct EqLaunch {
     float* z; long long z_d, z_inst, z_ch;         /* z[d*z_d + inst*z_inst + ch*z_ch + hop*128 + n] */
     const float* syn_rd; float* syn_wr; long long syn_d;      /* [d][inst][nCh][9][256] */
     int nCh, nInst, H;
+    const int* runFlag = nullptr;                  /* when set: the launch does nothing unless *runFlag != 0 (the re-run behind launch_eq_coop) */
 };
 /* done != nullptr: every workgroup (one per channel and instance, no time chunks) publishes its z and adds 1 to done[inst] when
  * it has finished — the decode kernel of launch_dec_stream consumes the instances as they complete */
@@ -194,6 +195,24 @@ struct EqDecodeTail {
     int* err;                                     /* [1] host-visible: set when a decode workgroup gave up waiting (the caller then runs the GEMM) */
 };
 bool launch_eq_decode(const EqLaunch& e, const EqDecodeTail& d, unsigned* done, unsigned target);
+
+/* The decode INSIDE the equaliser launch, z staying on chip (eq_kernels.hip MODE 3): order 7 (64 SH channels), 64 loudspeakers, one
+ * dense decoder, whole 16-hop sub-chunks.  The 64 channel workgroups of an instance exchange z through `ring`
+ * ([nInst][64][eq_coop_ring_slots()][16 x 128] floats) with per-(instance, sub-chunk) arrival counters `cnt` ([nInst][nSub], monotonic
+ * over launches: `target` = arrivals that complete a sub-chunk in THIS launch) and each decodes 32 of every sub-chunk's 2048 columns.
+ * Returns false when the shape does not fit.  `err` (host-visible) is set when a workgroup gave up waiting: the caller's guarded
+ * re-run launches (launch_eq with EqLaunch::runFlag, launch_band_gemm with runFlag) then recompute the step. */
+struct EqCoop {
+    float* ring; unsigned* cnt; unsigned target; int nSub;
+    float* Y; long long y_inst; int y_frame, y_row; int nRowsY, F, T;      /* (block and row strides as ints: scalar registers are short in this kernel) */
+    const float* Mfrag; int m_inst;
+    int* err;
+    int* giveUps;                                  /* device counter of the workgroups that gave up (diagnostics) */
+    /* -DEQ_COOP_CHECK builds only: buffer extents in bytes and a record of the first access outside them (the access is skipped) */
+    long long ringBytes = 0, cntBytes = 0, yBytes = 0, mBytes = 0; long long* dbg = nullptr;
+};
+bool launch_eq_coop(const EqLaunch& e, const EqCoop& c);
+int eq_coop_ring_slots();
 
 /* ---- the time-domain decode  out = sum_d M_d z_d  running BESIDE the equaliser kernel (gemm_kernels.hip) ----
  * A persistent grid of register-lean MFMA workgroups on the library's second stream: workgroup p takes the work items

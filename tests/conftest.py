@@ -24,8 +24,19 @@ def orc():
 
 @pytest.fixture(scope="session")
 def saf():
-    """The product API (libsaf_hip.so through ctypes). Fails loudly if the library is missing."""
+    """The product API (libsaf_hip.so through ctypes). Fails loudly if the library is missing.
+
+    On a GPU box torch's current stream becomes a stream of its own for the session: the tests hand
+    `torch.cuda.current_stream().cuda_stream` to `saf.set_stream`, and the legacy default stream is 0 — which the library
+    reads as "use your own (non-blocking) stream", i.e. NOT ordered against torch's kernels (a `torch.rand` input could still
+    be in flight when the library's kernel reads it).  With a real stream, torch's and the library's work are one queue."""
     from spatial_audio_framework_amd import api
     from spatial_audio_framework_amd._lib import load
     load()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_stream(torch.cuda.Stream())
+    except ImportError:
+        pass
     return api

@@ -308,6 +308,95 @@ def test_decode_beside_equaliser_is_bit_identical_to_sequential(saf, orc, path, 
     saf.set_stream(None)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_decode_inside_the_equaliser_launch_is_bit_identical_to_sequential(saf, orc, path, overlap, mode):
+    """setOverlap(3): the 64 channel workgroups of an instance pass z to each other through the write-through ring and
+    decode it inside the SAME launch (afstft_eq_kernel<1, 3>).  Bit for bit the output of equaliser kernel + GEMM — per-band
+    orders per instance, a stream cut into calls of different length (the ring and the counters are re-used, a 12-block call
+    wraps the ring), repeated calls on the same buffers — and equal to the oracle."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    F, order, nI, nF = 512, 7, 40, 24
+    path(mode)
+    cfgs = [(1, 1, 1 + i % 2, band_orders(7, 40 + i) if i % 3 else None) for i in range(nI)]
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    d_in = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+    st = (nF * 64 * 512, 64 * 512, 512)
+    res = {}
+    for ov in (0, 3):
+        overlap(ov)
+        for split in ((nF,), (4, 12, 8)):
+            bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+            d_out = torch.zeros(nI, nF, 64, 512, device="cuda")
+            f0 = 0
+            for n in split:
+                bt.process_ptr(d_in[:, f0:].data_ptr(), st, d_out[:, f0:].data_ptr(), st, n)
+                assert bt.lastOverlap() == ov
+                f0 += n
+            torch.cuda.synchronize()
+            assert bt.lastPath() == 1 and bt.decodeGiveUps() == 0
+            res[(ov, split)] = d_out.cpu().numpy()
+    assert np.array_equal(res[(3, (nF,))], res[(0, (nF,))])
+    assert np.array_equal(res[(3, (4, 12, 8))], res[(0, (nF,))])
+    x = d_in.cpu().numpy()
+    for i in (0, nI - 1):
+        a, b, n, o = cfgs[i]
+        oc = make(orc.AmbiDec, F, order, 29, a, b, n, 1, o)
+        yo = np.stack([oc.process(x[i, f], 64) for f in range(8)])
+        assert relrms(res[(3, (nF,))][i, :8], yo) < 3e-6, i
+    overlap(3)
+    bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+    overlap(0)
+    bs = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+    yo_, ys_ = torch.zeros(nI, nF, 64, 512, device="cuda"), torch.zeros(nI, nF, 64, 512, device="cuda")
+    for it in range(6):
+        xin = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+        overlap(3); bt.process_ptr(xin.data_ptr(), st, yo_.data_ptr(), st, nF)
+        overlap(0); bs.process_ptr(xin.data_ptr(), st, ys_.data_ptr(), st, nF)
+        torch.cuda.synchronize()
+        assert torch.equal(yo_, ys_), it
+    assert bt.decodeGiveUps() == 0
+    saf.set_stream(None)
+
+
+def test_cooperative_decode_that_gives_up_is_recomputed_by_the_guarded_launches(saf, path, overlap):
+    """A counter target nobody reaches makes every workgroup of the cooperative form give up its decode (bounded poll): the
+    host-visible flag then lets the two guarded launches behind (equaliser kernel + GEMM, which otherwise leave at once) compute
+    the call the ordinary way from the unflipped histories.  Same output bit for bit, the give-ups are counted, and the next
+    call (target restored) decodes in the launch again."""
+    import ctypes
+    import torch
+    from spatial_audio_framework_amd import _lib
+    L = _lib.load()
+    L.saf_hip_debug_coop_target_bias.argtypes = [ctypes.c_uint]; L.saf_hip_debug_coop_target_bias.restype = None
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    F, order, nI, nF = 512, 7, 3, 4
+    path(2)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    xs = [torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1 for _ in range(3)]
+    st = (nF * 64 * 512, 64 * 512, 512)
+    outs = {}
+    try:
+        for ov in (0, 3):
+            overlap(ov)
+            bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, 1, 1, 1, 1, None) for _ in range(nI)], nF)
+            ys = []
+            for k, x in enumerate(xs):
+                L.saf_hip_debug_coop_target_bias(1 << 20 if (ov == 3 and k == 1) else 0)
+                y = torch.zeros(nI, nF, 64, 512, device="cuda")
+                bt.process_ptr(x.data_ptr(), st, y.data_ptr(), st, nF)
+                torch.cuda.synchronize()
+                ys.append(y.cpu().numpy())
+            outs[ov] = ys
+            if ov == 3:
+                assert bt.lastOverlap() == 3 and bt.decodeGiveUps() == nI * 64
+    finally:
+        L.saf_hip_debug_coop_target_bias(0)
+    for k in range(3):
+        assert np.array_equal(outs[0][k], outs[3][k]), k
+    saf.set_stream(None)
+
+
 def test_equaliser_path_full_size_properties(saf, path, overlap):
     """bench size (256 instances x 64 blocks, every band its own order): linearity, instance independence, split invariance,
     and agreement with the transform path — the oracle is too slow here"""
