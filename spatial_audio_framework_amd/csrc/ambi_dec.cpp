@@ -106,7 +106,6 @@ struct DecPipeline {
     DevBuf<int> eqErr;              /* [2] see DecStreamLaunch::err */
     unsigned eqDoneBase = 0;
     int lastOverlap = 0;            /* 1: the last call ran the decode kernel beside the equaliser kernel; 3: inside it (cooperative form) */
-    DevBuf<float> coRing;           /* [nInst][64][ring slots][16 hops][128] z of the cooperative form: written and read inside ONE launch */
     DevBuf<unsigned> coCnt;         /* [nInst][coNSub] waves that have stored their z of a sub-chunk (zeroed before every launch) */
     int coNSub = 0;
     DevBuf<long long> coDbg;        /* -DEQ_COOP_CHECK builds: the first out-of-range access of the cooperative form */
@@ -489,17 +488,16 @@ struct DecPipeline {
             if (g_ambi_dec_overlap == 3 && eqD == 1 && nSH == SAF_MAXCH && nLS == 64 && H % 16 == 0 &&
                 out_frame < (1ll << 31) && out_ch < (1ll << 29) && out_frame >= 0 && out_ch >= 0) {
                 const int nSub = H / 16;
-                if (coRing.p == nullptr) coRing.alloc((size_t)nInst * SAF_MAXCH * eq_coop_ring_slots() * 16 * SAF_HOP);
                 if (coNSub < nSub) { coCnt.alloc((size_t)nInst * nSub); coNSub = nSub; }
                 errPin.ensure(1);
                 HIP_CHECK(hipMemsetAsync(coCnt.p, 0, (size_t)nInst * coNSub * sizeof(unsigned), stream()));
                 EqCoop c{};
-                c.ring = coRing.p; c.cnt = coCnt.p; c.target = 2u * SAF_MAXCH + g_coop_target_bias; c.nSub = coNSub;
+                c.cnt = coCnt.p; c.target = 2u * SAF_MAXCH + g_coop_target_bias; c.nSub = coNSub;
                 c.Y = d_out; c.y_inst = out_inst; c.y_frame = (int)out_frame; c.y_row = (int)out_ch; c.nRowsY = nLS; c.F = F; c.T = T;
                 c.Mfrag = Mfrag.p; c.m_inst = 2 * 64 * 64; c.err = errPin.p; c.giveUps = eqErr.p ? eqErr.p + 1 : nullptr;
 #ifdef EQ_COOP_CHECK
                 if (!coDbg.p) coDbg.alloc(8);
-                c.dbg = coDbg.p; c.ringBytes = (long long)coRing.n * 4; c.cntBytes = (long long)coCnt.n * 4; c.mBytes = (long long)Mfrag.n * 4;
+                c.dbg = coDbg.p; c.ringBytes = (long long)zbuf.n * 4; c.cntBytes = (long long)coCnt.n * 4; c.mBytes = (long long)Mfrag.n * 4;
                 c.yBytes = ((long long)(nInst - 1) * out_inst + (long long)(nFrames - 1) * out_frame + (long long)(nLS - 1) * out_ch + F) * 4;
 #endif
                 if (launch_eq_coop(q, c)) {
@@ -956,8 +954,8 @@ __attribute__((visibility("default"))) long long saf_hip_debug_batch_fetch(void*
 {   /* tests: the equaliser output buffer (0) or the cooperative form's ring (1), copied to the host */
     DecPipeline* b = (DecPipeline*)hBatch;
     HIP_CHECK(hipStreamSynchronize(stream()));
-    const float* src = which == 0 ? b->zbuf.p : which == 1 ? b->coRing.p : (const float*)b->coDbg.p;
-    const long long have = (long long)(which == 0 ? b->zbuf.n : which == 1 ? b->coRing.n : b->coDbg.n * 2);
+    const float* src = which == 0 ? b->zbuf.p : (const float*)b->coDbg.p;
+    const long long have = (long long)(which == 0 ? b->zbuf.n : b->coDbg.n * 2);
     if (!src) return 0;
     if (n > have) n = have;
     HIP_CHECK(hipMemcpy(dst, src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));

@@ -50,6 +50,9 @@ namespace saf {
 #ifndef EQ_BINB
 #define EQ_BINB 4           /* slots whose bin-pair reads are in flight together (bins phase) */
 #endif
+#ifndef EQ_OLA3
+#define EQ_OLA3 8          /* ... of the cooperative form: the decode's operand is in flight during the overlap-add, 16 registers less for the history */
+#endif
 #ifndef EQ_MINWAVES
 #define EQ_MINWAVES 3       /* waves per SIMD the one-output kernel is compiled for (168 registers) */
 #endif
@@ -158,13 +161,12 @@ __device__ __forceinline__ void decode_tail(const EqLaunch& e, const EqDecodeTai
  * in-order dispatch (observed, not promised: a poll that is not answered within ~0.2 s gives up, sets the host-visible flag, and the
  * guarded re-run launches behind this one — the plain kernel and the stand-alone GEMM — recompute the step from the untouched
  * input state). */
-#ifndef EQF_R
-#define EQF_R 8
-#endif
 #ifndef EQF_L
-#define EQF_L 2
+#define EQF_L 3
 #endif
-static_assert(EQF_R >= 2 * EQF_L + 1, "ring too short for the decode lag");
+#ifndef EQF_NB
+#define EQF_NB 32        /* B operand rows requested at the publish point (the rest after the first MFMAs) */
+#endif
 
 template <int D, int MODE>
 __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO_DS_PAIRING void afstft_eq_kernel(EqArgs g)      /* (MODE 2: small launches, occupancy does not matter) */
@@ -185,6 +187,7 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
     };
     auto twl = [&](int k) -> float2& { return PADTAB ? *reinterpret_cast<float2*>(s_ring + 16 * SLOT + 256 + 2 * k) : s_twl_[PADTAB ? 0 : k]; };
 
+    constexpr int OLA_N = MODE == 3 ? EQ_OLA3 : EQ_OLA;      /* frames per overlap-add pass */
     const EqLaunch& e = g.e;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ch = blockIdx.x, inst = blockIdx.y;
@@ -200,7 +203,10 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
      * dispatched earlier: arbitration is by priority, then age, so at equal priority the MFMA wave takes every issue slot it
      * can use and the vector waves beside it crawl (tools/probes/corun_clock.hip).  This kernel is the critical path of the
      * pair: its waves run at a raised priority, the MFMAs fill what they leave. */
-    if (g.prio) __builtin_amdgcn_s_setprio(3);
+    if (MODE != 3 && g.prio) __builtin_amdgcn_s_setprio(3);
+#ifdef EQ_COOP_PRIO
+    if (MODE == 3) __builtin_amdgcn_s_setprio(EQ_COOP_PRIO);
+#endif
     /* time chunks (grid z) add parallelism when few (channel, instance) workgroups exist: a chunk that does not start the launch
      * first runs the 16 hops before it without emitting them, which rebuilds its overlap-add history (identical arithmetic:
      * the outputs do not depend on how a launch is cut) */
@@ -257,14 +263,14 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
     float ca[D], cb[D], cg[D];                               /* the pair's 2 x 2 real map, see below */
 
     /* ---- overlap-add role: thread = sample position; frame history of the 9 hops before the launch ---- */
-    float gl[D][EQ_OLA + 9], gr[D][EQ_OLA + 9];
+    float gl[D][OLA_N + 9], gr[D][OLA_N + 9];
 #pragma unroll
     for (int d = 0; d < D; d++) {
         const float* h = e.syn_rd + (long long)d * e.syn_d + ((long long)inst * e.nCh + ch) * SAF_SYN_HIST * 256;
 #pragma unroll
         for (int i = 0; i < 9; i++) { const float a = h[i * 256 + tid], b = h[i * 256 + 128 + tid]; gl[d][i] = c0 > 0 ? 0.0f : a; gr[d][i] = c0 > 0 ? 0.0f : b; }
 #pragma unroll
-        for (int i = 9; i < EQ_OLA + 9; i++) gl[d][i] = gr[d][i] = 0.0f;
+        for (int i = 9; i < OLA_N + 9; i++) gl[d][i] = gr[d][i] = 0.0f;
     }
 
     /* input cursor (uniform): element offset of the next hop inside this instance's input */
@@ -361,75 +367,107 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
 #else
 #define CO_OK(kind, base, off, bytes, lo, extent, a, b) true
 #endif
-    __shared__ int s_coop[2];
-    bool coDead = false;                                     /* a poll gave up: no more decodes (the re-run launches recompute the step) */
+    bool coDead = false;                                     /* this wave gave up a poll: no more decodes (the re-run launches recompute the call) */
+    bool coReady = false;                                    /* the counter of sub-chunk coIt - 3 had reached the target when it was read one iteration ago */
+    unsigned coPoll = 0;                                     /* counter of sub-chunk coIt - 2, requested at the publish point, looked at after the overlap-add */
+    float coB[32];                                            /* B operand of the decode in flight: requested at the publish point, multiplied after the overlap-add */
     const int coHl = ch >> 2, coSo = (ch & 3) * 32;          /* this workgroup's 32 columns of a sub-chunk: hop coHl, samples coSo .. coSo + 31 */
     auto co_publish = [&](int k) {                           /* this wave's z of sub-chunk k is in memory (the caller has waited for its stores) */
         if (lane == 0 && CO_OK(1, uniform_gbase(g.co.cnt + (long long)inst * g.co.nSub + k), 0u, 4, g.co.cnt, g.co.cntBytes, k, 0))
             __hip_atomic_fetch_add(g.co.cnt + (long long)inst * g.co.nSub + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    auto co_decode = [&](int gsub) {                         /* out[:, slice] of sub-chunk gsub = M z[:, slice] */
-        int ok = 1;
-        if (lane == 0 && !coDead) {
-            ok = 0;
-            const unsigned* c = g.co.cnt + (long long)inst * g.co.nSub + gsub;
-            for (int itp = 0; itp < 400000 && CO_OK(2, uniform_gbase(c), 0u, 4, g.co.cnt, g.co.cntBytes, gsub, 0); itp++) {          /* bounded: ~0.2 s */
-                const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(v - g.co.target) >= 0) { ok = 1; break; }
-                __builtin_amdgcn_s_sleep(4);
+    auto co_request = [&](int k) {                           /* ask for the counter of sub-chunk k (every lane the same word) */
+        coPoll = __hip_atomic_load(g.co.cnt + (long long)inst * g.co.nSub + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    /* Every wave confirms for itself that all 128 waves of the instance have published sub-chunk d — normally it already knows
+     * (coReady), otherwise one lane polls, bounded — and a workgroup barrier stands between that and every load of the bytes
+     * (MI355X_MICROARCH.md "Valid forms", third row: sc1 stores of whole lines, per-wave adds after the wave's own wait, sc1 poll,
+     * barrier, sc1 loads). */
+    auto co_confirm = [&](int d) {
+#ifdef EQ_COOP_KNOBS                                         /* timing experiments only (results are wrong): SAF_HIP_COOP_KNOBS bits */
+        if (!(g.prio & 1))
+#endif
+        if (!coReady && !coDead) {
+            int ok = 0;
+#ifdef EQ_STAMPS
+            if (stampOn && lane == 0) stampAcc[11] += 1;
+#endif
+            if (lane == 0) {
+                const unsigned* c = g.co.cnt + (long long)inst * g.co.nSub + d;
+                for (int itp = 0; itp < 400000 && CO_OK(2, uniform_gbase(c), 0u, 4, g.co.cnt, g.co.cntBytes, d, 0); itp++) {          /* bounded: ~0.5 s */
+                    const unsigned v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(v - g.co.target) >= 0) { ok = 1; break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            ok = __builtin_amdgcn_readfirstlane(ok);
+            if (!ok) {
+                if (lane == 0) {
+                    __hip_atomic_store(g.co.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (g.co.giveUps) atomicAdd(g.co.giveUps, 1);
+                }
+                coDead = true;
             }
         }
-        if (lane == 0) s_coop[wv] = ok;
         lds_barrier();
-        const bool bothOk = s_coop[0] != 0 && s_coop[1] != 0;
-        lds_barrier();                                       /* (s_coop is rewritten by the next decode) */
-        if (!bothOk || coDead) {
-            if (!coDead && tid == 0) {
-                __hip_atomic_store(g.co.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (g.co.giveUps) atomicAdd(g.co.giveUps, 1);
-            }
-            coDead = true;
-            return;
-        }
+    };
+    /* every access below is  uniform base (scalar registers) + 32-bit lane offset: 64-bit addresses per lane for 32 + 32 + 16
+     * accesses would not fit beside the filterbank state */
+    auto co_loadB = [&](int d, int first, int count) {       /* B operand rows: SH channel c = 2 s + kh of the ring, this workgroup's 32 columns */
         int lq = lane;
-        asm volatile("" : "+v"(lq));                          /* (the lane offsets below are recomputed per decode: hoisted out of the sub-chunk loop they cost registers the filterbank needs) */
+        asm volatile("" : "+v"(lq));                          /* (lane offsets recomputed here: hoisted out of the sub-chunk loop they cost registers the filterbank needs) */
         const int kh = lq >> 5, lr = lq & 31;
-        const int slot = gsub % EQF_R;
-        /* every access is  uniform base (scalar registers) + 32-bit lane offset: 64-bit addresses per lane for 32 + 32 + 16 accesses
-         * would not fit beside the filterbank state */
-        /* B operand: SH channel c = 2 s + kh of the ring, this workgroup's 32 columns */
-        const gbase_t zb = uniform_gbase(g.co.ring + ((long long)inst * SAF_MAXCH * EQF_R + slot) * (SUB * SAF_HOP) + coHl * SAF_HOP + coSo);
-        const unsigned zl = (unsigned)(kh * EQF_R * (SUB * SAF_HOP) + lr) * 4u;
-        const unsigned zstep = 2u * EQF_R * (SUB * SAF_HOP) * 4u;                 /* bytes between the row pairs of consecutive steps */
-        const gbase_t Af = uniform_gbase(g.co.Mfrag + (long long)inst * g.co.m_inst + wv * 2048);
+        int io = inst;
+        asm volatile("" : "+s"(io));
+        int zch = (int)e.z_ch;
+        asm volatile("" : "+s"(zch));
+        const gbase_t zb = uniform_gbase(e.z + (long long)io * e.z_inst + (d * SUB + coHl) * SAF_HOP + coSo);
+        const unsigned zl = (unsigned)(kh * zch + lr) * 4u;
+        const long long zstep = 8ll * zch;                                         /* bytes between the row pairs of consecutive steps */
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+            if (i >= first && i < first + count)
+                coB[i] = !CO_OK(3, zb + i * zstep, zl, 4, e.z, g.co.ringBytes, d, i) ? 0.0f :
+                        __hip_atomic_load(reinterpret_cast<const float __attribute__((address_space(1)))*>(zb + i * zstep + zl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* global_load_dword sc1 */
+    };
+    auto co_finish = [&](int d, auto&& midway) {             /* out[:, slice] of sub-chunk d = M z[:, slice]; midway(): run when half the operand registers are free again */
+        int lq = lane, io = inst, yr = g.co.y_row;
+        asm volatile("" : "+v"(lq));
+        asm volatile("" : "+s"(io), "+s"(yr));                /* (bases and row offsets recomputed per decode too: as loop invariants they take the scalar registers of the loop) */
+        const int kh = lq >> 5, lr = lq & 31;
+        const gbase_t Af = uniform_gbase(g.co.Mfrag + (long long)io * g.co.m_inst + wv * 2048);
         const unsigned al = (unsigned)lq * 4u;
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        /* matrix fragments (L1 / L2 hits): two groups of eight in flight, the next group requested when its registers have been read */
+        float a0[8], a1[8];
+        auto ldA = [&](float (&a)[8], int s0_) {
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            /* half the operand rows in flight at a time (16 registers); the matrix fragments (L1 / L2 hits) in groups of four */
-            float b[16];
+            for (int i = 0; i < 8; i++) a[i] = !CO_OK(4, Af + (s0_ + i) * 256u, al, 4, g.co.Mfrag, g.co.mBytes, d, s0_ + i) ? 0.0f : gld<float>(Af + (s0_ + i) * 256u, al);
+        };
+        auto mm = [&](const float (&a)[8], int s0_) {
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                b[i] = !CO_OK(3, zb + (16 * half + i) * zstep, zl, 4, g.co.ring, g.co.ringBytes, gsub, 16 * half + i) ? 0.0f :
-                       __hip_atomic_load(reinterpret_cast<const float __attribute__((address_space(1)))*>(zb + (16 * half + i) * zstep + zl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      /* global_load_dword sc1 */
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float a[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) a[i] = !CO_OK(4, Af + (16 * half + 4 * q + i) * 256u, al, 4, g.co.Mfrag, g.co.mBytes, gsub, 16 * half + 4 * q + i) ? 0.0f : gld<float>(Af + (16 * half + 4 * q + i) * 256u, al);
-#pragma unroll
-                for (int i = 0; i < 4; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[4 * q + i], acc, 0, 0, 0);
-            }
-        }
-        const int hg = gsub * SUB + coHl, fr = hg / T;
-        const gbase_t Yb = uniform_gbase(g.co.Y + (long long)inst * g.co.y_inst + (long long)fr * g.co.y_frame + (hg - fr * T) * SAF_HOP + coSo + (long long)(wv * 32) * g.co.y_row);
-        const unsigned yl = (unsigned)(4 * kh * g.co.y_row + lr) * 4u;
+            for (int i = 0; i < 8; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], coB[s0_ + i], acc, 0, 0, 0);
+        };
+#ifdef EQ_COOP_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        ldA(a0, 0); ldA(a1, 8);
+        if (EQF_NB < 32) co_loadB(d, EQF_NB, 32 - EQF_NB);
+        mm(a0, 0);  __builtin_amdgcn_sched_barrier(0); ldA(a0, 16); __builtin_amdgcn_sched_barrier(0);
+        mm(a1, 8);  __builtin_amdgcn_sched_barrier(0); ldA(a1, 24); midway(); __builtin_amdgcn_sched_barrier(0);
+        mm(a0, 16); mm(a1, 24);
+#ifdef EQ_COOP_PRIO
+        __builtin_amdgcn_s_setprio(EQ_COOP_PRIO);
+#endif
+        const int hg = d * SUB + coHl, fr = hg / T;
+        const gbase_t Yb = uniform_gbase(g.co.Y + (long long)io * g.co.y_inst + (long long)fr * g.co.y_frame + (hg - fr * T) * SAF_HOP + coSo + (long long)(wv * 32) * yr);
+        const unsigned yl = (unsigned)(4 * kh * yr + lr) * 4u;
 #pragma unroll
         for (int r = 0; r < 16; r++)
-            if (CO_OK(5, Yb + (long long)((r & 3) + 8 * (r >> 2)) * g.co.y_row * 4, yl, 4, g.co.Y, g.co.yBytes, gsub, r))
-                gst<float>(Yb + (long long)((r & 3) + 8 * (r >> 2)) * g.co.y_row * 4, yl, acc[r]);
+            if (CO_OK(5, Yb + (long long)((r & 3) + 8 * (r >> 2)) * yr * 4, yl, 4, g.co.Y, g.co.yBytes, d, r))
+                gst<float>(Yb + (long long)((r & 3) + 8 * (r >> 2)) * yr * 4, yl, acc[r]);
     };
     int coIt = 0;
 
@@ -569,37 +607,60 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
          * reload of a spilled register is a vector-memory load whose wait (vmcnt is in order) also waits for these 16 loads —
          * measured as 4 000 idle cycles per sub-chunk in the bin phase.  The output stores below are younger than the loads, so
          * the fold's wait for the loads does not wait for them. */
-        if (more) {
+        if (MODE == 3) {
+            /* The publish point.  The ring stores of sub-chunk coIt - 1 are a whole iteration old (the wait is free): publish it.
+             * Then the decode of sub-chunk coIt - 3 starts — its B operand is requested HERE and multiplied after the overlap-add,
+             * like the filterbank's own input — and the counter of sub-chunk coIt - 2 is requested for the next iteration. */
+            if (coIt > 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                co_publish(coIt - 1);
+            }
+#ifdef EQ_COOP_KNOBS
+            if (!(g.prio & 4))
+#endif
+            if (coIt >= EQF_L) {
+                STAMP(7);
+                co_confirm(coIt - EQF_L);
+                STAMP(9);
+            }
+            /* (written in EVERY iteration — zeros while there is nothing to decode yet, loads also by a wave that has given up: an
+             * operand array that is written under a condition stays allocated around the whole loop.  No loads "ahead of time"
+             * from the hand-off buffer: they would leave lines in this XCD's L2 that the real loads then hit, stale.) */
+#if !defined(EQ_COOP_X) || EQ_COOP_X < 2
+            if (coIt >= EQF_L) co_loadB(coIt - EQF_L, 0, EQF_NB);
+            else {
+#pragma unroll
+                for (int i = 0; i < 32; i++) coB[i] = 0.0f;
+            }
+#endif
+            if (coIt >= EQF_L - 1) co_request(coIt - (EQF_L - 1));
+        }
+        auto request_input = [&]() {
             const unsigned offN = hop_off_bytes(min(s0 + SUB + (lane & 15), H - 1));
 #pragma unroll
             for (int i = 0; i < SUB; i++) xin[9 + i] = ld_at(__builtin_amdgcn_readlane(offN, i));
-        }
-        if (MODE == 3 && coIt > 0) {
-            /* publish sub-chunk coIt - 1: everything this wave issued before the 16 prefetch loads above has to be done — its ring
-             * stores are a whole iteration old */
-            if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            co_publish(coIt - 1);
-        }
+        };
+        if (more && MODE != 3) request_input();              /* (MODE 3: after the overlap-add — the decode's operand is in flight during it instead) */
         /* 5. 10-segment overlap-add, oldest frame first (afSTFT_internal.c:396-444): the hop emitted at s0 + t is
          *    sum_k w[k*128+n] * frame_{t-k}[(k&1)*128 + n] */
 #pragma unroll
-        for (int half = 0; half < SUB / EQ_OLA; half++) {
-            const int nh = min(EQ_OLA, n - half * EQ_OLA);
+        for (int half = 0; half < SUB / OLA_N; half++) {
+            const int nh = min(OLA_N, n - half * OLA_N);
             if (nh > 0) {
 #pragma unroll
                 for (int d = 0; d < D; d++) {
 #pragma unroll
                     /* the frames of the pass first (one LDS wait), then the sums; frames beyond the end of a partial pass are read
                      * (slots nobody uses) but neither stored nor kept (see the history update below) */
-                    for (int u = 0; u < EQ_OLA; u++) {
-                        const int uu = half * EQ_OLA + u;
+                    for (int u = 0; u < OLA_N; u++) {
+                        const int uu = half * OLA_N + u;
                         const float* slot = (d == 0 || uni) ? lag_slot(uu) : s_out1 + uu * SLOT;
                         if (D == 1) { gl[d][9 + u] = slot[tid]; gr[d][9 + u] = slot[128 + tid]; }
                         else { gl[d][9 + u] = slot[tid] * sc[d]; gr[d][9 + u] = slot[128 + tid] * sc[d]; }
                     }
 #pragma unroll
-                    for (int u = 0; u < EQ_OLA; u++) {
-                        const int uu = half * EQ_OLA + u;
+                    for (int u = 0; u < OLA_N; u++) {
+                        const int uu = half * OLA_N + u;
                         float acc = 0.0f;
 #pragma unroll
                         for (int k = 9; k >= 0; k--) acc = fmaf(w[k], (k & 1) ? gr[d][9 + u - k] : gl[d][9 + u - k], acc);
@@ -608,15 +669,15 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
                             gst<float>(uniform_gbase(zBase[d] + (long long)(s0 + uu) * SAF_HOP), (unsigned)(tid * 4), acc);
                         }
                     }
-                    if (nh == EQ_OLA) {
+                    if (nh == OLA_N) {
 #pragma unroll
-                        for (int i = 0; i < 9; i++) { gl[d][i] = gl[d][i + EQ_OLA]; gr[d][i] = gr[d][i + EQ_OLA]; }
+                        for (int i = 0; i < 9; i++) { gl[d][i] = gl[d][i + OLA_N]; gr[d][i] = gr[d][i + OLA_N]; }
                     } else {                                 /* partial pass: the 9 newest frames sit at nh .. nh+8 */
 #pragma unroll
                         for (int i = 0; i < 9; i++) {
                             float a = gl[d][i], b = gr[d][i];
 #pragma unroll
-                            for (int q = 1; q < EQ_OLA; q++) if (q == nh) { a = gl[d][i + q]; b = gr[d][i + q]; }
+                            for (int q = 1; q < OLA_N; q++) if (q == nh) { a = gl[d][i + q]; b = gr[d][i + q]; }
                             gl[d][i] = a; gr[d][i] = b;
                         }
                     }
@@ -628,7 +689,7 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
              * pieces (4 hops x 256 contiguous bytes per instruction) and stores them write-through: every 128-byte line of the ring
              * is written whole by one store instruction */
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const gbase_t rb = uniform_gbase(g.co.ring + (((long long)inst * SAF_MAXCH + ch) * EQF_R + (coIt % EQF_R)) * (SUB * SAF_HOP) + 64 * wv);
+            const gbase_t rb = uniform_gbase(zBase[0] + (long long)coIt * (SUB * SAF_HOP) + 64 * wv);
             int lq = lane;
             asm volatile("" : "+v"(lq));
             const unsigned rl = (unsigned)((lq >> 4) * SAF_HOP + 4 * (lq & 15)) * 4u;
@@ -642,10 +703,19 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
                  * five wait states before a memory instruction may read it — without them the store can go out with the OLD
                  * register contents, i.e. to a wild address), and a store of more than 8 bytes reads its data registers late
                  * (two wait states before they may be rewritten). */
-                if (CO_OK(6, q, rl, 16, g.co.ring, g.co.ringBytes, coIt, i))
+                if (CO_OK(6, q, rl, 16, e.z, g.co.ringBytes, coIt, i))
                 asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"(rl), "v"(v), "s"(q) : "memory");
             }
-            if (coIt >= EQF_L) co_decode(coIt - EQF_L);
+            /* the next sub-chunk's input is requested in the middle of the decode (when half its operand registers are free) */
+            bool asked = false;
+#ifdef EQ_COOP_KNOBS
+            if (!(g.prio & 6))
+#endif
+#if !defined(EQ_COOP_X) || EQ_COOP_X < 1
+            if (coIt >= EQF_L && !coDead) { STAMP(7); co_finish(coIt - EQF_L, [&]() { if (more) request_input(); }); asked = true; STAMP(10); }
+#endif
+            if (more && !asked) request_input();
+            coReady = coIt >= EQF_L - 1 && (int)((unsigned)__builtin_amdgcn_readfirstlane((int)coPoll) - g.co.target) >= 0;
             coIt++;
         }
         STAMP(7);                                            /* prefetch wait + OLA + stores */
@@ -678,7 +748,23 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
         /* drain: the last sub-chunk is published, then the decodes that lag behind */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         co_publish(coIt - 1);
-        for (int gsub = coIt - EQF_L; gsub < coIt; gsub++) if (gsub >= 0) co_decode(gsub);
+#ifdef EQ_COOP_KNOBS
+        if (!(g.prio & 4))
+#endif
+        for (int d = coIt - EQF_L; d < coIt; d++)
+            if (d >= 0) {
+                if (d > coIt - EQF_L) coReady = false;       /* (the first of them was asked about in the last iteration) */
+                STAMP(8);
+                co_confirm(d);
+                STAMP(9);
+#ifdef EQ_COOP_KNOBS
+                if (!(g.prio & 2))
+#endif
+#if !defined(EQ_COOP_X) || EQ_COOP_X < 3
+                if (!coDead) { co_loadB(d, 0, EQF_NB); co_finish(d, []() {}); }
+#endif
+                STAMP(10);
+            }
     }
     if (MODE == 1 || MODE == 2) {
         /* Publish this channel's z to the decode kernel that runs beside this one (launch_dec_stream, gemm_kernels.hip): every
@@ -789,16 +875,18 @@ bool launch_eq_coop(const EqLaunch& e, const EqCoop& c)
     g.win = dev_window(0, 0);
     g.twJ = dev_twiddles();
     g.tw256 = g.twJ + 128;
-    g.stamps = nullptr;
+    g.stamps = eq_stamps_buffer();
     g.chunk = e.H;
     g.done = nullptr; g.target = 0; g.dec = EqDecodeTail{}; g.prio = 0; g.co = c; g.runFlag = nullptr;
+#ifdef EQ_COOP_KNOBS
+    { const char* v = getenv("SAF_HIP_COOP_KNOBS"); g.prio = v ? atoi(v) : 0; }
+#endif
     KernelTimer kt("afstft_eq_coop");
     hipLaunchKernelGGL((afstft_eq_kernel<1, 3>), dim3(e.nCh, e.nInst, 1), dim3(128), 0, stream(), g);
     HIP_CHECK(hipGetLastError());
     return true;
 }
 
-int eq_coop_ring_slots() { return EQF_R; }
 
 }  // namespace saf
 

@@ -203,7 +203,7 @@ bool launch_eq_decode(const EqLaunch& e, const EqDecodeTail& d, unsigned* done, 
  * Returns false when the shape does not fit.  `err` (host-visible) is set when a workgroup gave up waiting: the caller's guarded
  * re-run launches (launch_eq with EqLaunch::runFlag, launch_band_gemm with runFlag) then recompute the step. */
 struct EqCoop {
-    float* ring; unsigned* cnt; unsigned target; int nSub;
+    unsigned* cnt; unsigned target; int nSub;
     float* Y; long long y_inst; int y_frame, y_row; int nRowsY, F, T;      /* (block and row strides as ints: scalar registers are short in this kernel) */
     const float* Mfrag; int m_inst;
     int* err;
@@ -212,7 +212,6 @@ struct EqCoop {
     long long ringBytes = 0, cntBytes = 0, yBytes = 0, mBytes = 0; long long* dbg = nullptr;
 };
 bool launch_eq_coop(const EqLaunch& e, const EqCoop& c);
-int eq_coop_ring_slots();
 
 /* ---- the time-domain decode  out = sum_d M_d z_d  running BESIDE the equaliser kernel (gemm_kernels.hip) ----
  * A persistent grid of register-lean MFMA workgroups on the library's second stream: workgroup p takes the work items

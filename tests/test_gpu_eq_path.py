@@ -309,60 +309,70 @@ def test_decode_beside_equaliser_is_bit_identical_to_sequential(saf, orc, path, 
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-def test_decode_inside_the_equaliser_launch_is_bit_identical_to_sequential(saf, orc, path, overlap, mode):
-    """setOverlap(3): the 64 channel workgroups of an instance pass z to each other through the write-through ring and
-    decode it inside the SAME launch (afstft_eq_kernel<1, 3>).  Bit for bit the output of equaliser kernel + GEMM — per-band
-    orders per instance, a stream cut into calls of different length (the ring and the counters are re-used, a 12-block call
-    wraps the ring), repeated calls on the same buffers — and equal to the oracle."""
+def test_decode_inside_the_equaliser_launch_matches_sequential_kernels(saf, orc, path, overlap, mode):
+    """setOverlap(3): the 64 channel workgroups of an instance pass z to each other through write-through stores and per-sub-chunk
+    counters and decode it inside the SAME launch (afstft_eq_kernel<1, 3>).  Against equaliser kernel + GEMM: the decode is the
+    same MFMA sequence on the same z, the filterbank a different instantiation of the same source (the compiler may contract
+    a * b + c differently: measured max |diff| 3e-7 at |y| <= 1.8), so the bound is 1e-6 rel. RMS and 2e-6 of the peak, per call
+    pattern — per-band orders per instance, a stream cut into calls of different length (the hand-off buffer and the counters
+    are re-used), repeated calls on the same buffers with fresh input, a small batch whose whole hand-off buffer stays in L2 —
+    and 3e-6 against the oracle."""
     import torch
     saf.set_stream(torch.cuda.current_stream().cuda_stream)
-    F, order, nI, nF = 512, 7, 40, 24
+    F, order = 512, 7
+
+    def close(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return relrms(a, b) < 1e-6 and np.abs(a - b).max() < 2e-6 * np.abs(b).max()
+
     path(mode)
-    cfgs = [(1, 1, 1 + i % 2, band_orders(7, 40 + i) if i % 3 else None) for i in range(nI)]
-    g = torch.Generator(device="cuda"); g.manual_seed(11)
-    d_in = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
-    st = (nF * 64 * 512, 64 * 512, 512)
-    res = {}
-    for ov in (0, 3):
-        overlap(ov)
-        for split in ((nF,), (4, 12, 8)):
-            bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
-            d_out = torch.zeros(nI, nF, 64, 512, device="cuda")
-            f0 = 0
-            for n in split:
-                bt.process_ptr(d_in[:, f0:].data_ptr(), st, d_out[:, f0:].data_ptr(), st, n)
-                assert bt.lastOverlap() == ov
-                f0 += n
+    for nI, nF, splits in ((40, 24, ((24,), (4, 12, 8))), (2, 8, ((8,), (4, 4)))):
+        cfgs = [(1, 1, 1 + i % 2, band_orders(7, 40 + i) if i % 3 else None) for i in range(nI)]
+        g = torch.Generator(device="cuda"); g.manual_seed(11)
+        d_in = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+        st = (nF * 64 * 512, 64 * 512, 512)
+        res = {}
+        for ov in (0, 3):
+            overlap(ov)
+            for split in splits:
+                bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+                d_out = torch.zeros(nI, nF, 64, 512, device="cuda")
+                f0 = 0
+                for n in split:
+                    bt.process_ptr(d_in[:, f0:].data_ptr(), st, d_out[:, f0:].data_ptr(), st, n)
+                    assert bt.lastOverlap() == ov
+                    f0 += n
+                torch.cuda.synchronize()
+                assert bt.lastPath() == 1 and bt.decodeGiveUps() == 0
+                res[(ov, split)] = d_out.cpu().numpy()
+        for split in splits:
+            assert close(res[(3, split)], res[(0, splits[0])]), (nI, split)
+        x = d_in.cpu().numpy()
+        for i in (0, nI - 1):
+            a, b, n, o = cfgs[i]
+            oc = make(orc.AmbiDec, F, order, 29, a, b, n, 1, o)
+            yo = np.stack([oc.process(x[i, f], 64) for f in range(8)])
+            assert relrms(res[(3, splits[0])][i, :8], yo) < 3e-6, i
+        overlap(3)
+        bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+        overlap(0)
+        bs = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
+        yo_, ys_ = torch.zeros(nI, nF, 64, 512, device="cuda"), torch.zeros(nI, nF, 64, 512, device="cuda")
+        for it in range(8):
+            xin = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+            overlap(3); bt.process_ptr(xin.data_ptr(), st, yo_.data_ptr(), st, nF)
+            overlap(0); bs.process_ptr(xin.data_ptr(), st, ys_.data_ptr(), st, nF)
             torch.cuda.synchronize()
-            assert bt.lastPath() == 1 and bt.decodeGiveUps() == 0
-            res[(ov, split)] = d_out.cpu().numpy()
-    assert np.array_equal(res[(3, (nF,))], res[(0, (nF,))])
-    assert np.array_equal(res[(3, (4, 12, 8))], res[(0, (nF,))])
-    x = d_in.cpu().numpy()
-    for i in (0, nI - 1):
-        a, b, n, o = cfgs[i]
-        oc = make(orc.AmbiDec, F, order, 29, a, b, n, 1, o)
-        yo = np.stack([oc.process(x[i, f], 64) for f in range(8)])
-        assert relrms(res[(3, (nF,))][i, :8], yo) < 3e-6, i
-    overlap(3)
-    bt = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
-    overlap(0)
-    bs = saf.AmbiDecBatch([make(saf.AmbiDec, F, order, 29, a, b, n, 1, o) for a, b, n, o in cfgs], nF)
-    yo_, ys_ = torch.zeros(nI, nF, 64, 512, device="cuda"), torch.zeros(nI, nF, 64, 512, device="cuda")
-    for it in range(6):
-        xin = torch.rand(nI, nF, 64, 512, device="cuda", generator=g) * 2 - 1
-        overlap(3); bt.process_ptr(xin.data_ptr(), st, yo_.data_ptr(), st, nF)
-        overlap(0); bs.process_ptr(xin.data_ptr(), st, ys_.data_ptr(), st, nF)
-        torch.cuda.synchronize()
-        assert torch.equal(yo_, ys_), it
-    assert bt.decodeGiveUps() == 0
+            assert close(yo_.cpu().numpy(), ys_.cpu().numpy()), (nI, it)
+        assert bt.decodeGiveUps() == 0
     saf.set_stream(None)
 
 
 def test_cooperative_decode_that_gives_up_is_recomputed_by_the_guarded_launches(saf, path, overlap):
     """A counter target nobody reaches makes every workgroup of the cooperative form give up its decode (bounded poll): the
     host-visible flag then lets the two guarded launches behind (equaliser kernel + GEMM, which otherwise leave at once) compute
-    the call the ordinary way from the unflipped histories.  Same output bit for bit, the give-ups are counted, and the next
+    the call the ordinary way from the unflipped histories.  Same output (1e-6 rel. RMS: the states the calls start from come from
+    two instantiations of the filterbank), the give-ups are counted, and the next
     call (target restored) decodes in the launch again."""
     import ctypes
     import torch
@@ -389,11 +399,11 @@ def test_cooperative_decode_that_gives_up_is_recomputed_by_the_guarded_launches(
                 ys.append(y.cpu().numpy())
             outs[ov] = ys
             if ov == 3:
-                assert bt.lastOverlap() == 3 and bt.decodeGiveUps() == nI * 64
+                assert bt.lastOverlap() == 3 and bt.decodeGiveUps() == nI * 64 * 2       # every wave counts its own give-up
     finally:
         L.saf_hip_debug_coop_target_bias(0)
     for k in range(3):
-        assert np.array_equal(outs[0][k], outs[3][k]), k
+        assert relrms(outs[3][k], outs[0][k]) < 1e-6, k
     saf.set_stream(None)
 
 

@@ -23,10 +23,10 @@ L.saf_hip_debug_eq_stamps(buf)
 n = 10
 for _ in range(n): bt.process_ptr(x.data_ptr(), st, y.data_ptr(), st, nF)
 L.saf_hip_debug_eq_stamps(buf)
-names = ["fold+prefetch", "barrier1", "FFT+lowbins", "barrier2", "bins: main pairs", "IFFT", "barrier3", "xl wait+OLA+stores", "bins: hybrid + DC", "-", "-", "-"]
+names = ["fold+prefetch", "barrier1", "FFT+lowbins", "barrier2", "bins: main pairs", "IFFT", "barrier3", "xl wait+OLA+stores", "bins: hybrid + DC", "coop: confirm", "coop: finish", "coop: slow polls (count)"]
 nwg = nI * 64 // 64
 for wv in range(2):
-    tot = sum(buf[wv * 12 + i] for i in range(12))
+    tot = sum(buf[wv * 12 + i] for i in range(11))
     print(f"wave {wv}: total cycles per workgroup-launch {tot / (n * nwg):.0f} (per sub-chunk {tot / (n * nwg * 16):.0f})")
-    for i in range(9):
-        print(f"   {names[i]:22s} {buf[wv * 12 + i] / (n * nwg * 16):9.0f} cycles / sub-chunk  {100.0 * buf[wv * 12 + i] / tot:5.1f} %")
+    for i in range(12):
+        print(f"   {names[i]:22s} {buf[wv * 12 + i] / (n * nwg * 16):9.2f} cycles / sub-chunk  {100.0 * buf[wv * 12 + i] / tot:5.1f} %")
