@@ -268,7 +268,10 @@ SAF_API int   saf_hip_ambi_dec_batch_lastPath(void* const hBatch);
  *  their output (the reference decodes every frame right after transforming it, ambi_dec.c:514-566).  Same arithmetic, same
  *  results (bit-identical to the two kernels run in sequence; 64 loudspeakers only).  setOverlap: 0 (default) never, 1 for launches
  *  of >= 3072 (instance, SH channel) pairs, 2 whenever the shape allows (tests).  Off by default: measured slower on MI355X
- *  (profiles/r03_overlap_experiment.txt).  batch_lastOverlap: 1 when the last call of the batch ran that way;
+ *  (profiles/r03_overlap_experiment.txt).  3: the decode INSIDE the equaliser launch — the channel workgroups of an instance pass z
+ *  to each other through write-through stores and per-sub-chunk counters and each decodes 1/64 of it (order 7, 64 loudspeakers,
+ *  one dense decoder, blocks in multiples of 16 hops; results within 1e-6 of the two kernels'); also measured slower
+ *  (profiles/r03_coop_experiment.txt).  batch_lastOverlap: 1 / 3 when the last call of the batch ran that way;
  *  batch_decodeGiveUps: how many decode workgroups ever gave up waiting for the equaliser kernel (their blocks were then computed
  *  by the fix-up launch): 0 in normal operation. */
 SAF_API void  saf_hip_ambi_dec_setOverlap(int mode);

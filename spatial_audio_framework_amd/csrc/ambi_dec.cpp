@@ -482,9 +482,10 @@ struct DecPipeline {
              * launch — the decode workgroups ride behind the channel workgroups and wait on the instance's counter. */
             static const int fuseSmall = []() { const char* v = getenv("SAF_HIP_AMBI_DEC_ONE_LAUNCH"); return v ? atoi(v) : 1; }();
             /* Optional (setOverlap(3)): the decode INSIDE the equaliser launch.  The 64 channel workgroups of an instance hand
-             * their z to each other through a small ring (write-through stores, per-sub-chunk counters) and each decodes its 32
-             * columns of every sub-chunk: z never takes the round trip through zbuf.  A workgroup that gives up waiting sets
-             * errPin and the two guarded launches behind recompute the call the ordinary way (the histories are still unflipped). */
+             * their z to each other through zbuf (write-through stores, per-sub-chunk counters) and each decodes its 32 columns
+             * of every sub-chunk three iterations later, while the data is still in the memory-side cache.  A wave that gives
+             * up waiting sets errPin and the two guarded launches behind recompute the call the ordinary way (the histories are
+             * still unflipped). */
             if (g_ambi_dec_overlap == 3 && eqD == 1 && nSH == SAF_MAXCH && nLS == 64 && H % 16 == 0 &&
                 out_frame < (1ll << 31) && out_ch < (1ll << 29) && out_frame >= 0 && out_ch >= 0) {
                 const int nSub = H / 16;

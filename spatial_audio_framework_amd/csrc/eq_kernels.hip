@@ -143,24 +143,30 @@ __device__ __forceinline__ void decode_tail(const EqLaunch& e, const EqDecodeTai
     }
 }
 
-/* MODE 3 — the decode INSIDE the equaliser launch, z never crossing HBM (order 7: 64 SH channels, 64 loudspeakers, one dense decoder).
- * The 64 channel workgroups of an instance hand their z to each other through a small ring (EQF_R sub-chunks of 16 hops per channel)
- * and each of them computes 1/64 of the instance's decode per sub-chunk: workgroup ch owns columns [32 ch, 32 ch + 32) of the
- * sub-chunk's 2048 samples — wave w the loudspeaker rows 32 w .. 32 w + 31 — as 32 k-pair steps of v_mfma_f32_32x32x2_f32 whose B
- * operand is one 4-byte load per lane (row = SH channel 2 s + (lane >> 5) of the ring, 128 contiguous bytes per half wave).
- *   iteration it:  [filterbank of sub-chunk it, z re-packed through the dead frame slots into 16-byte WRITE-THROUGH stores to ring
- *                  slot it % R]  [publish sub-chunk it - 1: its stores are a whole iteration old, s_waitcnt vmcnt(16) lets only
- *                  the next input prefetch stay in flight; one counter add per wave]  [decode of sub-chunk it - L: poll its
- *                  counter (128 arrivals), barrier, write-through-coherent loads (sc1), MFMAs, plain stores of the output block]
+/* MODE 3 — the decode INSIDE the equaliser launch (order 7: 64 SH channels, 64 loudspeakers, one dense decoder; optional, off by
+ * default: measured slower than the two kernels, profiles/r03_coop_experiment.txt).
+ * The 64 channel workgroups of an instance hand their z to each other through the pipeline's z buffer (EqLaunch::z, the same layout
+ * the stand-alone GEMM reads) and each of them computes 1/64 of the instance's decode per sub-chunk: workgroup ch owns columns
+ * [32 ch, 32 ch + 32) of the sub-chunk's 2048 samples — wave w the loudspeaker rows 32 w .. 32 w + 31 — as 32 k-pair steps of
+ * v_mfma_f32_32x32x2_f32 whose B operand is one 4-byte load per lane (row = SH channel 2 s + (lane >> 5), 128 contiguous bytes per
+ * half wave).
+ *   iteration it:  [filterbank of sub-chunk it]
+ *                  [publish point: sub-chunk it - 1 published (its stores are a whole iteration old: s_waitcnt vmcnt(0) is free;
+ *                   one counter add per wave); decode of sub-chunk it - L confirmed (normally known from the counter read one
+ *                   iteration ago, else a bounded poll) + workgroup barrier; its B operand requested (sc1 loads, in flight during
+ *                   the overlap-add); the counter of sub-chunk it - L + 1 requested]
+ *                  [overlap-add; z re-packed through the dead frame slots into 16-byte WRITE-THROUGH stores]
+ *                  [the decode's MFMAs (matrix fragments from L2, two groups of eight in flight; the next sub-chunk's input is
+ *                   requested half way), plain stores of the output block]
  * Hand-over form: MI355X_MICROARCH.md "Hand-offs measured with sc1 loads in place of the acquire", third row (every 128-byte line
  * written whole by ONE 16-byte-per-lane sc1 store instruction of one wave; every storing wave adds to the counter after its wait;
  * a 4-byte sc1 poll; a workgroup barrier between the poll and every load; 4-byte sc1 loads).  No L2 write-back, no L1 invalidate.
- * Ring reuse needs no second signal: a writer at iteration it has seen all-published(it - 1 - L), i.e. every workgroup is past
- * the reads of sub-chunk it - 2 L - 1; with R >= 2 L + 1 the slot it overwrites (sub-chunk it - R) is no longer read.
- * All 64 workgroups of an instance wait for each other, so they must be resident together: they are consecutive blocks of an
- * in-order dispatch (observed, not promised: a poll that is not answered within ~0.2 s gives up, sets the host-visible flag, and the
- * guarded re-run launches behind this one — the plain kernel and the stand-alone GEMM — recompute the step from the untouched
- * input state). */
+ * sc1 loads are L2-served: a hand-off address is read only after its counter says so and is not written twice in a launch (no
+ * ring), or a line read earlier would be hit again, stale.
+ * All 64 workgroups of an instance wait for each other.  They need not all be resident at once for that: workgroups are dispatched
+ * in order per XCD, so the lowest unfinished instance has all its workgroups resident or next in line (observed, not promised: a
+ * poll that is not answered within ~0.5 s gives up, sets the host-visible flag, and the guarded re-run launches behind this one —
+ * the plain kernel and the stand-alone GEMM — recompute the call from the untouched input state). */
 #ifndef EQF_L
 #define EQF_L 3
 #endif

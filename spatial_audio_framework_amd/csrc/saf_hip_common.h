@@ -196,12 +196,12 @@ struct EqDecodeTail {
 };
 bool launch_eq_decode(const EqLaunch& e, const EqDecodeTail& d, unsigned* done, unsigned target);
 
-/* The decode INSIDE the equaliser launch, z staying on chip (eq_kernels.hip MODE 3): order 7 (64 SH channels), 64 loudspeakers, one
- * dense decoder, whole 16-hop sub-chunks.  The 64 channel workgroups of an instance exchange z through `ring`
- * ([nInst][64][eq_coop_ring_slots()][16 x 128] floats) with per-(instance, sub-chunk) arrival counters `cnt` ([nInst][nSub], monotonic
- * over launches: `target` = arrivals that complete a sub-chunk in THIS launch) and each decodes 32 of every sub-chunk's 2048 columns.
- * Returns false when the shape does not fit.  `err` (host-visible) is set when a workgroup gave up waiting: the caller's guarded
- * re-run launches (launch_eq with EqLaunch::runFlag, launch_band_gemm with runFlag) then recompute the step. */
+/* The decode INSIDE the equaliser launch (eq_kernels.hip MODE 3): order 7 (64 SH channels), 64 loudspeakers, one dense decoder,
+ * whole 16-hop sub-chunks.  The 64 channel workgroups of an instance exchange z through EqLaunch::z (write-through stores) with
+ * per-(instance, sub-chunk) arrival counters `cnt` ([nInst][nSub], zeroed by the caller before the launch; `target` = arrivals
+ * that complete a sub-chunk = 2 waves x 64 workgroups) and each decodes 32 of every sub-chunk's 2048 columns.  Returns false when
+ * the shape does not fit.  `err` (host-visible) is set when a wave gave up waiting: the caller's guarded re-run launches
+ * (launch_eq with EqLaunch::runFlag, launch_band_gemm with runFlag) then recompute the call. */
 struct EqCoop {
     unsigned* cnt; unsigned target; int nSub;
     float* Y; long long y_inst; int y_frame, y_row; int nRowsY, F, T;      /* (block and row strides as ints: scalar registers are short in this kernel) */
