@@ -828,7 +828,9 @@ void launch_eq(const EqLaunch& e, unsigned* done)
         if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, 1>), grid, dim3(128), 0, stream(), g);
         else          hipLaunchKernelGGL((afstft_eq_kernel<2, 1>), grid, dim3(128), 0, stream(), g);
     } else {
-        if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, 0>), grid, dim3(128), 0, stream(), g);
+        /* (experiments: SAF_HIP_EQ_EXTRA_LDS reserves unused LDS per workgroup, i.e. lowers the occupancy) */
+        static const int extraLds = []() { const char* v = getenv("SAF_HIP_EQ_EXTRA_LDS"); return v ? atoi(v) : 0; }();
+        if (e.D == 1) hipLaunchKernelGGL((afstft_eq_kernel<1, 0>), grid, dim3(128), extraLds, stream(), g);
         else          hipLaunchKernelGGL((afstft_eq_kernel<2, 0>), grid, dim3(128), 0, stream(), g);
     }
     HIP_CHECK(hipGetLastError());
