@@ -31,11 +31,14 @@ typedef float _Complex float_complex;          /* saf_utility_complex.h:70 */
 /* ========================================================================== */
 /*                                 runtime                                    */
 /* ========================================================================== */
-/** Adopt a caller-owned hipStream_t (NULL: library-owned stream). All library work is enqueued on it. */
 /** One-block host-pointer calls (X_process, saf_matrixConv_apply, ...) let the kernels read / write the library's pinned
  *  staging blocks directly instead of copying them to and from device memory (default 1; env SAF_HIP_ZERO_COPY). */
 SAF_API void saf_hip_setZeroCopyIO(int enable);
 SAF_API int  saf_hip_getZeroCopyIO(void);
+/** Adopt a caller-owned hipStream_t: all work of the device-pointer entry points is enqueued on it, in order with the caller's own
+ *  work on that stream.  NULL selects a library-owned NON-BLOCKING stream — the legacy default stream (whose handle is also 0)
+ *  cannot be adopted, and work the caller queued on it is NOT ordered against the library's: a caller that produces inputs on
+ *  the default stream synchronises (or uses a stream of its own, as tests/conftest.py does) before calling. */
 SAF_API void  saf_hip_set_stream(void* hipStream);
 SAF_API void* saf_hip_get_stream(void);
 SAF_API void  saf_hip_synchronize(void);
