@@ -476,7 +476,7 @@ struct DecPipeline {
             ds.z = zbuf.p; ds.z_d = zD; ds.z_inst = zInst; ds.z_ch = zCh; ds.D = eqD; ds.nCh = nSH; ds.nInst = nInst;
             ds.Y = d_out; ds.y_inst = out_inst; ds.y_frame = out_frame; ds.y_row = out_ch;
             ds.Mfrag = Mfrag.p; ds.m_inst = 2 * 64 * 64; ds.nRowsY = nLS; ds.F = F; ds.nFrames = nFrames;
-            const bool overlap = g_ambi_dec_overlap != 0 && (g_ambi_dec_overlap == 2 || ((long long)nInst * nSH >= 3072 && H >= 32)) &&
+            const bool overlap = (g_ambi_dec_overlap == 1 || g_ambi_dec_overlap == 2) && (g_ambi_dec_overlap == 2 || ((long long)nInst * nSH >= 3072 && H >= 32)) &&
                                  !on_private_stream() && dec_stream_supported(ds);      /* (one side stream per process: not from a handle's own stream) */
             /* Small launches (the one-block host-pointer call is bound by launches, not by the chip): equaliser and decode in ONE
              * launch — the decode workgroups ride behind the channel workgroups and wait on the instance's counter. */
