@@ -368,6 +368,29 @@ def test_decode_inside_the_equaliser_launch_matches_sequential_kernels(saf, orc,
     saf.set_stream(None)
 
 
+def test_cooperative_form_declines_shapes_it_does_not_take(saf, path, overlap):
+    """setOverlap(3) with a call that is not a whole number of 16-hop sub-chunks (3 blocks = 12 hops) or a two-decoder pipeline:
+    the sequential kernels run (lastOverlap 0) and the output is theirs bit for bit."""
+    import torch
+    saf.set_stream(torch.cuda.current_stream().cuda_stream)
+    path(2)
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    for nF, two in ((3, False), (4, True)):
+        x = torch.rand(12, nF, 64, 512, device="cuda", generator=g) * 2 - 1
+        st = (nF * 64 * 512, 64 * 512, 512)
+        ys = []
+        for ov in (0, 3):
+            overlap(ov)
+            bt = saf.AmbiDecBatch([make(saf.AmbiDec, 512, 7, 29, 1, 3 if two else 1, 1, 1, None) for _ in range(12)], nF)
+            y = torch.zeros_like(x)
+            bt.process_ptr(x.data_ptr(), st, y.data_ptr(), st, nF)
+            torch.cuda.synchronize()
+            assert bt.lastPath() == 1 and bt.lastOverlap() == 0
+            ys.append(y)
+        assert torch.equal(ys[0], ys[1])
+    saf.set_stream(None)
+
+
 def test_cooperative_decode_that_gives_up_is_recomputed_by_the_guarded_launches(saf, path, overlap):
     """A counter target nobody reaches makes every workgroup of the cooperative form give up its decode (bounded poll): the
     host-visible flag then lets the two guarded launches behind (equaliser kernel + GEMM, which otherwise leave at once) compute
