@@ -450,11 +450,19 @@ __global__ __launch_bounds__(128, (D == 1 && MODE != 2) ? EQ_MINWAVES : 2) EQ_NO
         float a0[8], a1[8];
         auto ldA = [&](float (&a)[8], int s0_) {
 #pragma unroll
+#if defined(EQ_COOP_Y) && (EQ_COOP_Y & 2)             /* timing experiment: no matrix loads */
+            for (int i = 0; i < 8; i++) a[i] = (float)(s0_ + i);
+#else
             for (int i = 0; i < 8; i++) a[i] = !CO_OK(4, Af + (s0_ + i) * 256u, al, 4, g.co.Mfrag, g.co.mBytes, d, s0_ + i) ? 0.0f : gld<float>(Af + (s0_ + i) * 256u, al);
+#endif
         };
         auto mm = [&](const float (&a)[8], int s0_) {
 #pragma unroll
+#if defined(EQ_COOP_Y) && (EQ_COOP_Y & 1)             /* timing experiment: one vector FMA in place of every MFMA */
+            for (int i = 0; i < 8; i++) acc[(s0_ + i) & 15] = fmaf(a[i], coB[s0_ + i], acc[(s0_ + i) & 15]);
+#else
             for (int i = 0; i < 8; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], coB[s0_ + i], acc, 0, 0, 0);
+#endif
         };
 #ifdef EQ_COOP_PRIO
         __builtin_amdgcn_s_setprio(0);
