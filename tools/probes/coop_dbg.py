@@ -1,4 +1,6 @@
-"""one cooperative-form call, small, for diagnostics"""
+"""Diagnostics for the cooperative form (setOverlap(3)): one call of nI instances x nF blocks on the sequential kernels and on the
+cooperative form, where the outputs differ, and — on a -DEQ_COOP_CHECK build — the first out-of-range access the kernel recorded.
+usage: python tools/probes/coop_dbg.py <instances> <blocks> [path mode 1|2]"""
 import sys, numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import spatial_audio_framework_amd.api as saf
@@ -29,18 +31,6 @@ for ov in (0, 3):
         dbg = np.zeros(8, np.int64)
         got = L.saf_hip_debug_batch_fetch(bt.hb, 2, dbg.ctypes.data, 16)
         print("dbg", got, dbg.tolist(), flush=True)
-    if False:
-        buf = np.zeros(nI * 64 * (8 if ov == 3 else 1) * 2048, np.float32)
-        got = L.saf_hip_debug_batch_fetch(bt.hb, 1 if ov == 3 else 0, buf.ctypes.data, buf.size)
-        print("fetched", got)
-        zz = buf.reshape(nI, 64, -1, 16, 128)[:, :, 0]
-        if ov == 0: z0 = zz
-        else:
-            dz = np.abs(zz - z0)
-            print("z: max diff", dz.max(), "max", np.abs(z0).max(), "n bad", (dz > 0).sum())
-            bad = np.argwhere(dz > 0)
-            print("cols", sorted(set(bad[:, 3]))[:40]); print("chs", sorted(set(bad[:, 1]))); print("hops", sorted(set(bad[:, 2])))
-            if len(bad): print("example", bad[0], zz[tuple(bad[0])], z0[tuple(bad[0])])
 d = np.abs(res[0] - res[1])
 print("max diff", d.max(), "ref max", np.abs(res[0]).max(), "equal", np.array_equal(res[0], res[1]))
 if d.max() > 0:
