@@ -452,6 +452,7 @@ def test_equaliser_path_full_size_properties(saf, path, overlap):
             bt.process_ptr(x[:, f0:].data_ptr(), st, y[:, f0:].data_ptr(), st, n)
             f0 += n
         torch.cuda.synchronize()
+        go.lastOverlap = bt.lastOverlap()
         return y
 
     ya, yb = go(a, 1), go(b, 1)
@@ -470,5 +471,11 @@ def test_equaliser_path_full_size_properties(saf, path, overlap):
     # persistent decode workgroups — bit for bit the sequential result
     overlap(2)
     assert torch.equal(go(a, 1), ya)
+    # ... and the decode INSIDE the equaliser launch: 16 sub-chunks per workgroup, 16 384 workgroups of which at most 1 536 are
+    # resident at a time (the hand-off must not depend on co-residency of an instance with the instances around it)
+    overlap(3)
+    yc = go(a, 1)
+    assert go.lastOverlap == 3
+    assert float((yc - ya).norm() / ya.norm()) < 1e-6 and float((yc - ya).abs().max() / ya.abs().max()) < 2e-6
     overlap(0)
     saf.set_stream(None)
